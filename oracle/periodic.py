@@ -1,0 +1,101 @@
+"""Oracle (test infrastructure only): incompressible Navier-Stokes residual on a periodic box.
+
+PARITY UNPINNED BY THE REFERENCE.  The reference (mhw32/neural-navier-stokes) has no periodic
+Fourier path, no 9-point Laplacian and no assembled residual (SURVEY.md section 8, row a17;
+motivation: src/neural_spectral/derivations/derivation.tex:25-59 "Neural Residual PDEs", NS
+form src/direct_fd/derivations/derivation.tex:64-68).  These functions DEFINE the operators
+the HIP residual engine must reproduce; they are pinned by analytic known-answers
+(Taylor-Green vortex: the spectral residual vanishes to O(nu^2 dt), the FD residual converges
+at 2nd order) in tests/test_oracle_periodic.py rather than by reference fixtures.
+
+Definitions (fields [..., nx, ny], axis 0 = x, axis 1 = y, periodic, x_i = i*Lx/nx):
+
+  r_u   = (u - u_prev)/dt + u u_x + v u_y + p_x/rho - nu lap(u)
+  r_v   = (v - v_prev)/dt + u v_x + v v_y + p_y/rho - nu lap(v)
+  r_div = u_x + v_y
+
+FD back-end: 2nd-order central first derivatives; lap = 5-point, or the 9-point
+"Mehrstellen" form  d_xx + d_yy + (dx^2+dy^2)/12 * d_xx d_yy  (for dx == dy this is the classic
+[1 4 1; 4 -20 4; 1 4 1]/(6 h^2) stencil).
+Spectral back-end: d/dx <-> i*kx (the Nyquist mode of an even-length axis is zeroed for odd
+derivatives, the usual convention that keeps the result real), lap <-> -(kx^2 + ky^2).
+"""
+import numpy as np
+
+
+def _r(f, s, axis):
+    return np.roll(f, s, axis=axis)
+
+
+def fd_derivs(f, dx, dy, stencil=5):
+    """Returns (f_x, f_y, lap f) with periodic wrap."""
+    xm, xp = _r(f, 1, -2), _r(f, -1, -2)
+    ym, yp = _r(f, 1, -1), _r(f, -1, -1)
+    fx = (xp - xm) / (2 * dx)
+    fy = (yp - ym) / (2 * dy)
+    dxx = (xp - 2 * f + xm)
+    dyy = (yp - 2 * f + ym)
+    lap = dxx / dx**2 + dyy / dy**2
+    if stencil == 9:
+        corners = (_r(xm, 1, -1) + _r(xm, -1, -1) + _r(xp, 1, -1) + _r(xp, -1, -1))
+        dxxdyy = corners - 2 * (xm + xp + ym + yp) + 4 * f
+        lap = lap + (dx**2 + dy**2) / 12. * dxxdyy / (dx**2 * dy**2)
+    elif stencil != 5:
+        raise ValueError("stencil must be 5 or 9")
+    return fx, fy, lap
+
+
+def fd_residual(u, v, p, u_prev, v_prev, dt, dx, dy, rho, nu, stencil=5):
+    ux, uy, lu = fd_derivs(u, dx, dy, stencil)
+    vx, vy, lv = fd_derivs(v, dx, dy, stencil)
+    px, py, _ = fd_derivs(p, dx, dy, 5)
+    r_u = (u - u_prev) / dt + u * ux + v * uy + px / rho - nu * lu
+    r_v = (v - v_prev) / dt + u * vx + v * vy + py / rho - nu * lv
+    return r_u, r_v, ux + vy
+
+
+def wavenumbers(n, L):
+    """(k for odd derivatives [Nyquist zeroed], k for even derivatives), length n, FFT order."""
+    k = 2 * np.pi * np.fft.fftfreq(n, d=L / n)
+    k1 = k.copy()
+    if n % 2 == 0:
+        k1[n // 2] = 0.0
+    return k1, k
+
+
+def spectral_derivs(f, Lx, Ly):
+    """Returns (f_x, f_y, lap f) via rfft2 / irfft2 (computed in float64 complex)."""
+    nx, ny = f.shape[-2], f.shape[-1]
+    kx1, kx = wavenumbers(nx, Lx)
+    ky1, ky = wavenumbers(ny, Ly)
+    nyh = ny // 2 + 1
+    F = np.fft.rfft2(f.astype(np.float64))
+    KX1, KX = kx1[:, None], kx[:, None]
+    KY1, KY = ky1[None, :nyh].copy(), np.abs(ky[None, :nyh])
+    fx = np.fft.irfft2(1j * KX1 * F, s=(nx, ny))
+    fy = np.fft.irfft2(1j * KY1 * F, s=(nx, ny))
+    lap = np.fft.irfft2(-(KX**2 + KY**2) * F, s=(nx, ny))
+    return fx, fy, lap
+
+
+def spectral_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu):
+    ux, uy, lu = spectral_derivs(u, Lx, Ly)
+    vx, vy, lv = spectral_derivs(v, Lx, Ly)
+    px, py, _ = spectral_derivs(p, Lx, Ly)
+    r_u = (u - u_prev) / dt + u * ux + v * uy + px / rho - nu * lu
+    r_v = (v - v_prev) / dt + u * vx + v * vy + py / rho - nu * lv
+    return r_u, r_v, ux + vy
+
+
+def taylor_green(nx, ny, t, nu, rho=1.0, Lx=2 * np.pi, Ly=2 * np.pi):
+    """Analytic decaying Taylor-Green vortex on [0,Lx)x[0,Ly) (exact NS solution for
+    Lx = Ly = 2*pi): u = cos x sin y F, v = -sin x cos y F, p = -rho/4 (cos 2x + cos 2y) F^2,
+    F = exp(-2 nu t)."""
+    x = Lx * np.arange(nx) / nx
+    y = Ly * np.arange(ny) / ny
+    X, Y = np.meshgrid(x, y, indexing='ij')
+    F = np.exp(-2 * nu * t)
+    u = np.cos(X) * np.sin(Y) * F
+    v = -np.sin(X) * np.cos(Y) * F
+    p = -rho / 4. * (np.cos(2 * X) + np.cos(2 * Y)) * F * F
+    return u, v, p

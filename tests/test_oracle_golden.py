@@ -1,0 +1,173 @@
+"""The CPU oracle vs golden vectors captured from the reference (oracle/capture.py).
+
+float64 throughout.  Stencil operators must agree to ~1 ulp-level (1e-13 rel); anything that goes
+through a LAPACK factorisation in the reference (ADI solves, eig/inv) to 1e-9 / 1e-8.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unpack_bcs, rel_l2, KINDS, SIDES
+from oracle import boundary as OB
+from oracle import chorin_fd as OC
+from oracle import direct_fd as OD
+from oracle import chorin_spectral as OS
+
+
+# ------------------------------------------------------------------ boundary (a1)
+def test_boundary_single():
+    g = load_golden('boundary.npz')
+    val, dx, dy = float(g['single_value']), float(g['single_dx']), float(g['single_dy'])
+    for kind in KINDS:
+        for side in SIDES:
+            A = g['A0'].copy()
+            r = OB.apply_bc(A, kind, side, val, dx, dy)
+            assert r is A
+            np.testing.assert_array_equal(A, g['%s_%s' % (kind, side)])
+
+
+@pytest.mark.parametrize('name', ['u', 'v', 'p', 'mixed'])
+def test_boundary_lists_corner_order(name):
+    g = load_golden('boundary.npz')
+    A = g['S0'].copy()
+    OB.apply_bc_list(A, unpack_bcs(g, 'list_%s_bc' % name))
+    np.testing.assert_array_equal(A, g['list_' + name])
+
+
+# ------------------------------------------------------------------ chorin_fd (a2-a6)
+@pytest.mark.parametrize('n', [16, 64])
+def test_chorin_fd_operators(n):
+    g = load_golden('chorin_fd_ops_%d.npz' % n)
+    dt, rho, nu, beta, dx, dy = g['params']
+    u, v, u1, v1, p0 = g['u'], g['v'], g['u1'], g['v1'], g['p0']
+    ui, vi = OC.explicit_predictor(u, v, u1, v1, dt, dx, dy, nu)
+    np.testing.assert_array_equal(ui, g['pred_explicit_ui'])
+    np.testing.assert_array_equal(vi, g['pred_explicit_vi'])
+    ui, vi = OC.semi_implicit_predictor(u, v, u1, v1, dt, dx, dy, nu)
+    assert rel_l2(ui, g['pred_semi_implicit_ui']) < 1e-12
+    assert rel_l2(vi, g['pred_semi_implicit_vi']) < 1e-12
+    a, b = OC.correction(u, v, p0, dt, dx, dy)
+    np.testing.assert_array_equal(a, g['corr_u'])
+    np.testing.assert_array_equal(b, g['corr_v'])
+
+
+@pytest.mark.parametrize('n', [16, 64])
+@pytest.mark.parametrize('nit', [3, 50, 400])
+def test_chorin_fd_sor_bitwise_and_sweep_count(n, nit):
+    g = load_golden('chorin_fd_ops_%d.npz' % n)
+    dt, rho, nu, beta, dx, dy = g['params']
+    p = g['press_p0_nit%d' % nit].copy()
+    r, (sweeps, err) = OC.get_pressure(g['press_ui'], g['press_vi'], p, dt, dx, dy, rho, beta, nit,
+                                       return_info=True)
+    assert r is p
+    np.testing.assert_array_equal(p, g['press_p_nit%d' % nit])        # wavefront == lexicographic
+    assert sweeps == int(g['press_sweeps_nit%d' % nit])
+    assert err == float(g['press_err_nit%d' % nit])
+    assert sweeps <= nit - 1                                          # 'it' starts at 1 (:183)
+
+
+def test_sor_wavefront_equals_lexicographic_loop():
+    rng = np.random.default_rng(5)
+    p = rng.standard_normal((9, 12))
+    C = rng.standard_normal((9, 12))
+    a = OC.sor_sweep_wavefront(p.copy(), C, 0.2, 0.3, 1.25)
+    b = OC.sor_sweep_lexicographic(p.copy(), C, 0.2, 0.3, 1.25)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_sor_tolerance_path_is_exercised():
+    g = load_golden('chorin_fd_ops_16.npz')
+    assert int(g['press_sweeps_nit400']) < 399       # stopped by err <= tol, not by the cap
+    assert float(g['press_err_nit400']) <= OC.SOR_TOL
+
+
+@pytest.mark.parametrize('n', [16, 64])
+@pytest.mark.parametrize('method', ['explicit', 'semi_implicit'])
+def test_chorin_fd_full_step(n, method):
+    g = load_golden('chorin_fd_ops_%d.npz' % n)
+    dt, rho, nu, beta, dx, dy = g['params']
+    u_bc, v_bc, p_bc = (unpack_bcs(g, k + '_bc') for k in 'uvp')
+    p = 0.01 * g['p0'].copy()
+    a, b, c, (sweeps, _) = OC.step(0.1 * g['u'], 0.1 * g['v'], 0.1 * g['u1'], 0.1 * g['v1'], p, u_bc, v_bc,
+                                    p_bc, dt, dx, dy, rho, nu, beta, 20, method, return_info=True)
+    tol = 0 if method == 'explicit' else 1e-11
+    for got, key in ((a, 'u'), (b, 'v'), (c, 'p')):
+        assert rel_l2(got, g['step_%s_%s' % (method, key)]) <= tol
+    assert sweeps == int(g['step_%s_sweeps' % method])
+
+
+@pytest.mark.parametrize('case', [(16, 'explicit', 0.1), (16, 'semi_implicit', 0.1), (64, 'explicit', 0.02),
+                                  (64, 'explicit', 0.01), (64, 'semi_implicit', 0.02),
+                                  (64, 'semi_implicit', 0.01)])
+def test_chorin_fd_cavity_trajectory(case):
+    n, method, nu = case
+    g = load_golden('chorin_fd_cavity_%d_%s_nu%g.npz' % (n, method, nu))
+    dt, rho, nu_, beta, dx, dy = g['params']
+    u_bc, v_bc, p_bc = OB.cavity_bcs(dx, dy)
+    z = np.zeros((n, n))
+    ul, vl, pl = OC.simulate(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, int(g['nt']), int(g['nit']),
+                             dt, rho, nu_, beta, method)
+    sel = slice(None) if n == 16 else [0, -1]
+    tol = 0 if method == 'explicit' else 1e-9
+    assert rel_l2(ul[sel], g['u']) <= tol
+    assert rel_l2(vl[sel], g['v']) <= tol
+    assert rel_l2(pl[sel], g['p']) <= tol
+
+
+# ------------------------------------------------------------------ direct_fd (a7-a9)
+@pytest.mark.parametrize('n', [16, 64])
+def test_direct_fd_operators(n):
+    g = load_golden('direct_fd_ops_%d.npz' % n)
+    dt, rho, nu, dx, dy = g['params']
+    u_bc, v_bc, p_bc = (unpack_bcs(g, k + '_bc') for k in 'uvp')
+    b = OD.build_up_b(g['u'], g['v'], dt, dx, dy, rho)
+    np.testing.assert_array_equal(b, g['b'])
+    for nit in (1, 50):
+        p = g['p0'].copy()
+        r = OD.pressure_poisson(p, 1e-3 * b, p_bc, dx, dy, nit)
+        assert r is p
+        np.testing.assert_array_equal(p, g['poisson_nit%d' % nit])
+    u, v, p = 0.1 * g['u'], 0.1 * g['v'], 0.01 * g['p0']
+    OD.step(u, v, p, u_bc, v_bc, p_bc, dt, dx, dy, rho, nu, 20)
+    np.testing.assert_array_equal(u, g['step_u'])
+    np.testing.assert_array_equal(v, g['step_v'])
+    np.testing.assert_array_equal(p, g['step_p'])
+
+
+@pytest.mark.parametrize('n', [16, 64])
+def test_direct_fd_cavity_trajectory(n):
+    g = load_golden('direct_fd_cavity_%d.npz' % n)
+    dt, rho, nu, dx, dy = g['params']
+    u_bc, v_bc, p_bc = OB.cavity_bcs(dx, dy)
+    z = np.zeros((n, n))
+    ul, vl, pl = OD.simulate(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, int(g['nt']), int(g['nit']),
+                             dt, rho, nu)
+    sel = slice(None) if n == 16 else [0, -1]
+    np.testing.assert_array_equal(ul[sel], g['u'])
+    np.testing.assert_array_equal(vl[sel], g['v'])
+    np.testing.assert_array_equal(pl[sel], g['p'])
+
+
+# ------------------------------------------------------------------ chorin_spectral (a10-a11)
+@pytest.mark.parametrize('N', [9, 17, 33, 51])
+def test_chorin_spectral_matrices(N):
+    g = load_golden('chorin_spectral_%d.npz' % N)
+    np.testing.assert_array_equal(OS.gauss_lobatto_points(N), g['x_i'])
+    np.testing.assert_array_equal(OS.T_matrix(N), g['Tx'])
+    np.testing.assert_allclose(OS.inv_T_matrix(N), g['Tx_inv'], rtol=1e-14, atol=0)
+    assert rel_l2(OS.D_matrix(N), g['Dx']) < 1e-14
+    assert rel_l2(OS.D_sqr_matrix(N), g['Dx_sqr']) < 1e-13
+    assert rel_l2(OS.D_matrix_degrees_minus_2(N), g['DPx']) < 1e-14
+    S = OS.Setup(N, N, unpack_bcs(g, 'u_bc'), unpack_bcs(g, 'v_bc'))
+    assert rel_l2(S.DxDPx, g['DxDPx']) < 1e-13
+
+
+@pytest.mark.parametrize('N', [17, 51])
+def test_chorin_spectral_single_step(N):
+    g = load_golden('chorin_spectral_%d.npz' % N)
+    dt, rho = g['params']
+    S = OS.Setup(N, N, unpack_bcs(g, 'u_bc'), unpack_bcs(g, 'v_bc'))
+    ui, vi = OS.predictor_step(S, g['un'], g['vn'], g['un1'], g['vn1'], dt)
+    assert np.isrealobj(ui)
+    assert rel_l2(ui, g['pred_ui']) < 1e-8 and rel_l2(vi, g['pred_vi']) < 1e-8
+    a, b, c = OS.correction_step(S, g['pred_ui'], g['pred_vi'], g['p'], dt, rho)
+    assert rel_l2(a, g['corr_u']) < 1e-8 and rel_l2(b, g['corr_v']) < 1e-8 and rel_l2(c, g['corr_p']) < 1e-8

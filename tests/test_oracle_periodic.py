@@ -1,0 +1,83 @@
+"""Analytic pins for the periodic-box residual oracle (oracle/periodic.py).
+
+The reference has no periodic/Fourier/9-point/assembled-residual code (SURVEY.md section 8 row
+a17), so these operators are pinned by known answers instead of reference fixtures:
+  * Taylor-Green is an exact NS solution: the spectral residual is O(nu^2 dt) (time
+    discretisation only), the divergence is zero to rounding;
+  * the FD residual converges at 2nd order (5-point and 9-point);
+  * the 9-point Laplacian equals the classic [1 4 1; 4 -20 4; 1 4 1]/(6h^2) stencil for dx == dy;
+  * spectral derivatives of single Fourier modes are exact, the Nyquist mode is dropped for odd
+    derivatives and kept for the Laplacian.
+"""
+import numpy as np
+import pytest
+
+from oracle import periodic as OP
+
+NU, RHO, DT, T0 = 2 * np.pi / 1000, 1.0, 1e-3, 0.1
+L = 2 * np.pi
+
+
+def tg_inputs(n):
+    u, v, p = OP.taylor_green(n, n, T0, NU, RHO)
+    up, vp, _ = OP.taylor_green(n, n, T0 - DT, NU, RHO)
+    return u, v, p, up, vp
+
+
+def test_spectral_residual_vanishes_on_taylor_green():
+    u, v, p, up, vp = tg_inputs(64)
+    ru, rv, rd = OP.spectral_residual(u, v, p, up, vp, DT, L, L, RHO, NU)
+    # (u - u_prev)/dt = u_t + O(dt u_tt) with u_tt = 4 nu^2 u  ->  residual ~ 2 nu^2 dt |u|
+    bound = 2.5 * NU**2 * DT
+    assert np.abs(ru).max() < bound and np.abs(rv).max() < bound
+    assert np.abs(rd).max() < 1e-13
+
+
+@pytest.mark.parametrize('stencil', [5, 9])
+def test_fd_residual_second_order(stencil):
+    errs = []
+    for n in (32, 64, 128):
+        u, v, p, up, vp = tg_inputs(n)
+        h = L / n
+        ru, rv, rd = OP.fd_residual(u, v, p, up, vp, DT, h, h, RHO, NU, stencil)
+        errs.append(max(np.abs(ru).max(), np.abs(rv).max()))
+    assert 3.6 < errs[0] / errs[1] < 4.4 and 3.6 < errs[1] / errs[2] < 4.4
+
+
+def test_nine_point_is_classic_stencil():
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((12, 10))
+    h = 0.3
+    _, _, lap9 = OP.fd_derivs(f, h, h, 9)
+    r = lambda a, sx, sy: np.roll(np.roll(a, sx, 0), sy, 1)
+    edge = r(f, 1, 0) + r(f, -1, 0) + r(f, 0, 1) + r(f, 0, -1)
+    corner = r(f, 1, 1) + r(f, 1, -1) + r(f, -1, 1) + r(f, -1, -1)
+    classic = (4 * edge + corner - 20 * f) / (6 * h * h)
+    np.testing.assert_allclose(lap9, classic, rtol=1e-12, atol=1e-11)
+
+
+def test_spectral_derivs_single_modes_and_nyquist():
+    n = 16
+    x = L * np.arange(n) / n
+    X, Y = np.meshgrid(x, x, indexing='ij')
+    f = np.sin(3 * X) * np.cos(2 * Y)
+    fx, fy, lap = OP.spectral_derivs(f, L, L)
+    np.testing.assert_allclose(fx, 3 * np.cos(3 * X) * np.cos(2 * Y), atol=1e-12)
+    np.testing.assert_allclose(fy, -2 * np.sin(3 * X) * np.sin(2 * Y), atol=1e-12)
+    np.testing.assert_allclose(lap, -13 * f, atol=1e-11)
+    nyq = np.cos((n // 2) * X) + 0 * Y                   # the x-Nyquist mode
+    fx, fy, lap = OP.spectral_derivs(nyq, L, L)
+    assert np.abs(fx).max() < 1e-12 and np.abs(fy).max() < 1e-12
+    np.testing.assert_allclose(lap, -(n // 2) ** 2 * nyq, atol=1e-10)
+
+
+def test_batched_leading_axes_and_non_square():
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal((3, 2, 8, 12))
+    fx, fy, lap = OP.spectral_derivs(f, L, 2 * L)
+    a, b, c = OP.spectral_derivs(f[1, 1], L, 2 * L)
+    np.testing.assert_allclose(fx[1, 1], a, atol=1e-13)
+    np.testing.assert_allclose(lap[1, 1], c, atol=1e-12)
+    gx, gy, gl = OP.fd_derivs(f, 0.1, 0.2, 9)
+    a, b, c = OP.fd_derivs(f[2, 0], 0.1, 0.2, 9)
+    np.testing.assert_array_equal(gl[2, 0], c)
