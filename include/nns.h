@@ -1,0 +1,171 @@
+/*
+ * nns.h -- C ABI of libnns_hip.so, the MI355X (gfx950) residual engine behind the call surface of
+ * mhw32/neural-navier-stokes (src/boundary.py, src/chorin_fd, src/direct_fd, src/chorin_spectral,
+ * src/neural_spectral).  The reference is pure Python with no FFI of its own:
+ * the entry points below are what a ctypes binding on the reference side would bind for each of
+ * its operators; every declaration cites the reference symbol (file:line) it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in
+ *     _host; buffers are caller-owned and caller-allocated (workspace sizes via the *_workspace
+ *     query functions); the library never allocates or frees device memory in a launch function;
+ *   - one call = one stream-ordered enqueue on `stream` (a hipStream_t; NULL = default stream),
+ *     no host synchronisation unless the function says so;
+ *   - fields are C-contiguous [batch, nx, ny]; element [b][i][j] at (b*nx + i)*ny + j;
+ *     suffix _f32 / _f64 is the storage type of the fields (arithmetic is done in that type
+ *     unless stated);
+ *   - return value: 0 on success, a negative nns_status otherwise; never throws, never aborts;
+ *     nns_last_error() returns a thread-local message for the last failure;
+ *   - boundary lists (nns_bc_list) are small host structs passed by pointer and copied into
+ *     kernel arguments.
+ */
+#ifndef NNS_H
+#define NNS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNS_VERSION_MAJOR 0
+#define NNS_VERSION_MINOR 1
+
+typedef enum nns_status {
+    NNS_OK = 0,
+    NNS_ERR_INVALID_ARG = -1,   /* bad size / null pointer / unsupported combination       */
+    NNS_ERR_UNSUPPORTED = -2,   /* valid request this build has no kernel for              */
+    NNS_ERR_LAUNCH = -3,        /* HIP reported a launch/runtime error (see last_error)    */
+    NNS_ERR_WORKSPACE = -4      /* workspace too small                                     */
+} nns_status;
+
+/* ---- boundary conditions: src/boundary.py:1-86 ------------------------------------------- */
+enum { NNS_BC_DIRICHLET = 0, NNS_BC_NEUMANN = 1 };                 /* .type,  :32,:54          */
+enum { NNS_SIDE_LEFT = 0,   /* A[0, :]   src/boundary.py:39-40 */
+       NNS_SIDE_RIGHT = 1,  /* A[-1, :]  :41-42 */
+       NNS_SIDE_BOTTOM = 2, /* A[:, 0]   :43-44 */
+       NNS_SIDE_TOP = 3 };  /* A[:, -1]  :45-46 */
+#define NNS_MAX_BC 8
+typedef struct nns_bc_list {
+    int32_t n;                       /* number of entries, applied in list order (corners!)   */
+    int32_t kind[NNS_MAX_BC];
+    int32_t side[NNS_MAX_BC];
+    double value[NNS_MAX_BC];
+    double dx[NNS_MAX_BC];           /* each BC object carries its own dx, dy (:23)            */
+    double dy[NNS_MAX_BC];
+} nns_bc_list;
+
+const char* nns_last_error(void);
+int nns_version(void);                                  /* major*1000 + minor                  */
+/* Fills name (<= cap bytes), CU count, and HBM bytes of the current device. */
+int nns_device_info(char* name_host, int cap, int* cu_count_host, size_t* hbm_bytes_host);
+
+/* DirichletBoundaryCondition.apply / NeumannBoundaryCondition.apply (src/boundary.py:34-48,
+ * :56-86) for a whole list, in list order, in place, on every grid of the batch. */
+int nns_bc_apply_f32(float* A, int batch, int nx, int ny, const nns_bc_list* bcs_host, void* stream);
+int nns_bc_apply_f64(double* A, int batch, int nx, int ny, const nns_bc_list* bcs_host, void* stream);
+
+/* ---- chorin_fd: src/chorin_fd/simulate.py ------------------------------------------------ */
+/* _explicit_predictor_step (:63-91): AB2 advection (both differences along axis 0 -- reference
+ * quirk) + AB2 5-point diffusion on the interior, edges copied from un/vn.  out: ui, vi. */
+int nns_fd_predictor_explicit_f32(const float* un, const float* vn, const float* un1, const float* vn1,
+                                  float* ui, float* vi, int batch, int nx, int ny,
+                                  double dt, double dx, double dy, double nu, void* stream);
+int nns_fd_predictor_explicit_f64(const double* un, const double* vn, const double* un1, const double* vn1,
+                                  double* ui, double* vi, int batch, int nx, int ny,
+                                  double dt, double dx, double dy, double nu, void* stream);
+
+/* _semi_implicit_predictor_step (:93-167): AB2 advection + Crank-Nicolson ADI; the dense
+ * np.linalg.solve calls (:137,:153,:159,:165) become constant-coefficient Thomas solves, one
+ * thread per column, BOTH along axis 0 as in the reference (needs nx == ny).  work: 4*batch*nx*ny
+ * elements of scratch. */
+size_t nns_fd_predictor_adi_workspace(int batch, int nx, int ny, int elem_size);
+int nns_fd_predictor_adi_f32(const float* un, const float* vn, const float* un1, const float* vn1,
+                             float* ui, float* vi, float* work, int batch, int nx, int ny,
+                             double dt, double dx, double dy, double nu, void* stream);
+int nns_fd_predictor_adi_f64(const double* un, const double* vn, const double* un1, const double* vn1,
+                             double* ui, double* vi, double* work, int batch, int nx, int ny,
+                             double dt, double dx, double dy, double nu, void* stream);
+
+/* dx2dy2C of _get_pressure (:186-188): backward-difference divergence RHS, zero on the edge. */
+int nns_fd_pressure_rhs_f32(const float* ui, const float* vi, float* C, int batch, int nx, int ny,
+                            double dt, double dx, double dy, double rho, void* stream);
+int nns_fd_pressure_rhs_f64(const double* ui, const double* vi, double* C, int batch, int nx, int ny,
+                            double dt, double dx, double dy, double rho, void* stream);
+
+/* The SOR loop of _get_pressure (:190-200): in-place lexicographic Gauss-Seidel with
+ * over-relaxation, evaluated in anti-diagonal wavefront order (bitwise-identical update order),
+ * several sweeps in flight skewed by two fronts.  Stops after the first sweep whose
+ * max|p - pPrev| <= tol, or after max_sweeps (= nit-1) sweeps.  p is updated in place.
+ * info[2*b] = sweeps done, info[2*b+1] = last err (as the field type), per grid b.
+ * work: nns_fd_sor_workspace() bytes. One workgroup per grid ("replicas only" across GPUs). */
+size_t nns_fd_sor_workspace(int batch, int nx, int ny, int elem_size);
+int nns_fd_sor_f32(float* p, const float* C, float* info, void* work, int batch, int nx, int ny,
+                   double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
+int nns_fd_sor_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny,
+                   double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
+
+/* _correction_step (:204-210): u = u* - dt/(2dx) d0x p, v = v* - dt/(2dy) d0y p; edges from u*. */
+int nns_fd_correction_f32(const float* ui, const float* vi, const float* p, float* u, float* v,
+                          int batch, int nx, int ny, double dt, double dx, double dy, void* stream);
+int nns_fd_correction_f64(const double* ui, const double* vi, const double* p, double* u, double* v,
+                          int batch, int nx, int ny, double dt, double dx, double dy, void* stream);
+
+/* ---- direct_fd: src/direct_fd/simulate.py (axis 1 = x there) ------------------------------- */
+/* _build_up_b (:56-66). */
+int nns_fd_build_b_f32(const float* u, const float* v, float* b, int batch, int nx, int ny,
+                       double dt, double dx, double dy, double rho, void* stream);
+int nns_fd_build_b_f64(const double* u, const double* v, double* b, int batch, int nx, int ny,
+                       double dt, double dx, double dy, double rho, void* stream);
+/* _pressure_poisson (:68-88): exactly nit Jacobi sweeps, the p BC list applied after every sweep.
+ * p is updated in place; tmp is a scratch field of the same size (ping-pong). */
+int nns_fd_jacobi_f32(float* p, float* tmp, const float* b, int batch, int nx, int ny,
+                      double dx, double dy, int nit, const nns_bc_list* p_bc_host, void* stream);
+int nns_fd_jacobi_f64(double* p, double* tmp, const double* b, int batch, int nx, int ny,
+                      double dx, double dy, int nit, const nns_bc_list* p_bc_host, void* stream);
+/* The u, v update of step (:98-118): upwind advection, central grad p / (2 rho), 5-point
+ * diffusion.  un, vn -> u, v (edges copied); must not alias. */
+int nns_fd_direct_update_f32(const float* un, const float* vn, const float* p, float* u, float* v,
+                             int batch, int nx, int ny, double dt, double dx, double dy,
+                             double rho, double nu, void* stream);
+int nns_fd_direct_update_f64(const double* un, const double* vn, const double* p, double* u, double* v,
+                             int batch, int nx, int ny, double dt, double dx, double dy,
+                             double rho, double nu, void* stream);
+
+/* ---- periodic-box Navier-Stokes residual (north-star operators; no reference symbol, SURVEY.md
+ *      section 8 row a17; defined by oracle/periodic.py) --------------------------------------- */
+/* r_u = (u-u_prev)/dt + u u_x + v u_y + p_x/rho - nu lap u ; r_v likewise ; r_div = u_x + v_y.
+ * FD back-end: central differences, stencil = 5 or 9 (Mehrstellen) point Laplacian. */
+int nns_fd_residual_f32(const float* u, const float* v, const float* p, const float* u_prev,
+                        const float* v_prev, float* r_u, float* r_v, float* r_div,
+                        int batch, int nx, int ny, double dt, double dx, double dy,
+                        double rho, double nu, int stencil, void* stream);
+int nns_fd_residual_f64(const double* u, const double* v, const double* p, const double* u_prev,
+                        const double* v_prev, double* r_u, double* r_v, double* r_div,
+                        int batch, int nx, int ny, double dt, double dx, double dy,
+                        double rho, double nu, int stencil, void* stream);
+/* Spectral back-end: d/dx <-> i kx, lap <-> -|k|^2 via LDS-resident 1-D FFTs (the operators are
+ * separable, so no 2-D transform is materialised): pass 1 transforms columns (axis 0) and leaves
+ * the x-part of the residual in r_u, r_v, r_div; pass 2 transforms rows (axis 1) and completes
+ * them in place.  nx, ny powers of two in [64, 1024].  precise != 0: forward transforms and the
+ * spectral multiply run in float64 (inverse in float32) -- needed for 1e-5 rel-L2 because forward
+ * rounding noise is amplified by k; precise == 0: all-float32 (about 2e-4 rel-L2 at 1024). */
+int nns_spec_residual_f32(const float* u, const float* v, const float* p, const float* u_prev,
+                          const float* v_prev, float* r_u, float* r_v, float* r_div,
+                          int batch, int nx, int ny, double dt, double Lx, double Ly,
+                          double rho, double nu, int precise, void* stream);
+/* The two halves of nns_spec_residual_f32, exposed for slab-decomposed (multi-GPU) use:
+ * x-pass on a column slab [nx, ny_local] (needs complete columns), y-pass on a row slab
+ * [nx_local, ny] (needs complete rows) which reads the x-parts from r_* and finishes them. */
+int nns_spec_residual_xpass_f32(const float* u, const float* v, const float* p,
+                                float* r_u, float* r_v, float* r_div, int batch, int nx, int ny,
+                                double Lx, double rho, double nu, int precise, void* stream);
+int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, const float* u_prev,
+                                const float* v_prev, float* r_u, float* r_v, float* r_div,
+                                int batch, int nx, int ny, double dt, double Ly,
+                                double rho, double nu, int precise, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNS_H */

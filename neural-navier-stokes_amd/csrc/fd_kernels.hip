@@ -1,0 +1,492 @@
+// Finite-difference operators of chorin_fd / direct_fd and boundary-condition application,
+// as HIP kernels for gfx950.  Compiled with -ffp-contract=off: every expression keeps the
+// reference's operation order (see oracle/chorin_fd.py, oracle/direct_fd.py), so the float64
+// instantiations agree with the NumPy reference to rounding (no FMA contraction).
+//
+// All of these are HBM-bound streaming stencils (<= 3 FLOP/B): one thread per grid point,
+// j (the contiguous axis) on threadIdx.x so every wave reads/writes 256 contiguous bytes per
+// field; the i+-1 / j+-1 re-reads are served by L1/L2.  Algorithmic bytes per point are listed
+// at each kernel (T = sizeof element).
+#include "nns_common.h"
+
+using namespace nns;
+
+namespace {
+
+constexpr int kTX = 256;   // threads along j (4 waves)
+
+inline dim3 grid2d(int batch, int nx, int ny) { return dim3((ny + kTX - 1) / kTX, nx, batch); }
+
+// ------------------------------------------------------------------------------------------
+// Boundary conditions  (src/boundary.py:34-48, :56-86)
+// ------------------------------------------------------------------------------------------
+// One BC of the list applied by all threads of a block to the grid at A (global or LDS).
+template <typename T, typename P>
+__device__ __forceinline__ void bc_apply_one(P A, int nx, int ny, int kind, int side, T value, T dx, T dy,
+                                             int tid, int nthreads) {
+    if (side == NNS_SIDE_LEFT || side == NNS_SIDE_RIGHT) {
+        const int i = side == NNS_SIDE_LEFT ? 0 : nx - 1;
+        const int in = side == NNS_SIDE_LEFT ? 1 : nx - 2;
+        for (int j = tid; j < ny; j += nthreads) {
+            T r;
+            if (kind == NNS_BC_DIRICHLET) r = value;
+            else r = side == NNS_SIDE_LEFT ? A[(size_t)in * ny + j] - dx * value : A[(size_t)in * ny + j] + dx * value;
+            A[(size_t)i * ny + j] = r;
+        }
+    } else {
+        const int j = side == NNS_SIDE_BOTTOM ? 0 : ny - 1;
+        const int jn = side == NNS_SIDE_BOTTOM ? 1 : ny - 2;
+        for (int i = tid; i < nx; i += nthreads) {
+            T r;
+            if (kind == NNS_BC_DIRICHLET) r = value;
+            else r = side == NNS_SIDE_BOTTOM ? A[(size_t)i * ny + jn] - dy * value : A[(size_t)i * ny + jn] + dy * value;
+            A[(size_t)i * ny + j] = r;
+        }
+    }
+}
+
+// The whole list in list order (later entries win at corners, and a Neumann entry may read a
+// corner an earlier entry wrote): one workgroup per grid, a barrier between entries.
+template <typename T, typename P>
+__device__ __forceinline__ void bc_apply_list(P A, int nx, int ny, const BcListDev<T>& bcs, int tid, int nthreads) {
+    for (int k = 0; k < bcs.n; ++k) {
+        bc_apply_one<T>(A, nx, ny, bcs.kind[k], bcs.side[k], bcs.value[k], bcs.dx[k], bcs.dy[k], tid, nthreads);
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bc_apply_kernel(T* A, int nx, int ny, BcListDev<T> bcs) {
+    T* g = A + (size_t)blockIdx.x * nx * ny;
+    bc_apply_list<T>(g, nx, ny, bcs, threadIdx.x, blockDim.x);
+}
+
+template <typename T>
+int bc_apply(T* A, int batch, int nx, int ny, const nns_bc_list* h, hipStream_t s) {
+    if (!A || !field_args_ok(batch, nx, ny)) return fail(NNS_ERR_INVALID_ARG, "bc_apply: bad field args (batch=%d nx=%d ny=%d)", batch, nx, ny);
+    BcListDev<T> d;
+    if (int rc = make_bc_dev<T>(h, d)) return rc;
+    if (d.n == 0) return NNS_OK;
+    hipLaunchKernelGGL(bc_apply_kernel<T>, dim3(batch), dim3(256), 0, s, A, nx, ny, d);
+    return check_launch("bc_apply");
+}
+
+// ------------------------------------------------------------------------------------------
+// chorin_fd._explicit_predictor_step  (src/chorin_fd/simulate.py:63-91)
+// algorithmic traffic: read un,vn,un1,vn1 + write ui,vi = 6T B/pt
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct PredK { T dt, two_dx, two_dy, dx2, dy2, dt_nu; };
+
+template <typename T>
+__global__ __launch_bounds__(kTX) void predictor_explicit_kernel(const T* __restrict__ un, const T* __restrict__ vn,
+                                                                  const T* __restrict__ un1, const T* __restrict__ vn1,
+                                                                  T* __restrict__ ui, T* __restrict__ vi,
+                                                                  int nx, int ny, PredK<T> k) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t base = (size_t)blockIdx.z * nx * ny, c = base + (size_t)i * ny + j;
+    const T uc = un[c], vc = vn[c];
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { ui[c] = uc; vi[c] = vc; return; }
+    const size_t xp = c + ny, xm = c - ny, yp = c + 1, ym = c - 1;
+    const T u1c = un1[c], v1c = vn1[c];
+    const T three_half = (T)1.5, half = (T)0.5, two = (T)2;
+    {
+        const T e = un[xp], w = un[xm], e1 = un1[xp], w1 = un1[xm];
+        const T adv = uc * (e - w) / k.two_dx + vc * (e - w) / k.two_dy;            // :73-74 (x-difference twice)
+        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (e1 - w1) / k.two_dy;      // :75-76
+        const T lap = (e - two * uc + w) / k.dx2 + (un[yp] - two * uc + un[ym]) / k.dy2;
+        const T lap1 = (e1 - two * u1c + w1) / k.dx2 + (un1[yp] - two * u1c + un1[ym]) / k.dy2;
+        ui[c] = uc - k.dt * (three_half * adv - half * adv1) + k.dt_nu * (three_half * lap - half * lap1);
+    }
+    {
+        const T e = vn[xp], w = vn[xm], e1 = vn1[xp], w1 = vn1[xm];
+        const T adv = uc * (e - w) / k.two_dx + vc * (e - w) / k.two_dy;            // :82-83
+        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (e1 - w1) / k.two_dy;
+        const T lap = (e - two * vc + w) / k.dx2 + (vn[yp] - two * vc + vn[ym]) / k.dy2;
+        const T lap1 = (e1 - two * v1c + w1) / k.dx2 + (vn1[yp] - two * v1c + vn1[ym]) / k.dy2;
+        vi[c] = vc - k.dt * (three_half * adv - half * adv1) + k.dt_nu * (three_half * lap - half * lap1);
+    }
+}
+
+template <typename T>
+int predictor_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T* vi, int batch, int nx, int ny,
+                       double dt, double dx, double dy, double nu, hipStream_t s) {
+    if (!un || !vn || !un1 || !vn1 || !ui || !vi || !field_args_ok(batch, nx, ny))
+        return fail(NNS_ERR_INVALID_ARG, "fd_predictor_explicit: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
+    PredK<T> k{(T)dt, (T)(2 * dx), (T)(2 * dy), (T)(dx * dx), (T)(dy * dy), (T)(dt * nu)};
+    hipLaunchKernelGGL(predictor_explicit_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, un1, vn1, ui, vi, nx, ny, k);
+    return check_launch("fd_predictor_explicit");
+}
+
+// ------------------------------------------------------------------------------------------
+// chorin_fd._semi_implicit_predictor_step  (src/chorin_fd/simulate.py:93-167)
+// One thread per (field, column j): both tridiagonal solves run along axis 0 (reference quirk),
+// so a column never needs another column's intermediate; all global accesses are coalesced
+// across the threads of a wave (adjacent j).  The modified diagonal cp[i] of the constant-
+// coefficient Thomas factorisation is the same for every column: each thread carries it in a
+// register on the way down, thread 0 parks it in LDS for the way back up.
+// algorithmic traffic: read 4 fields, write 2, + the ut/vt round trip (4T) = 10T B/pt.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct AdiK { T dt, two_dx, two_dy, dx2, dy2, dt_nu, half_dt, cx, cy, a_diag, b_diag; };
+
+template <typename T>
+__global__ __launch_bounds__(64) void predictor_adi_kernel(const T* __restrict__ un, const T* __restrict__ vn,
+                                                            const T* __restrict__ un1, const T* __restrict__ vn1,
+                                                            T* __restrict__ ui, T* __restrict__ vi, T* __restrict__ work,
+                                                            int nx, int ny, AdiK<T> k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* cpA = reinterpret_cast<T*>(smem_raw);       // [nx] modified diagonal, first solve
+    T* cpB = cpA + nx;                             // [nx] second solve
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool is_v = blockIdx.y == 1;
+    const size_t base = (size_t)blockIdx.z * nx * ny;
+    const T* f = (is_v ? vn : un) + base;          // the field being advanced
+    const T* f1 = (is_v ? vn1 : un1) + base;
+    const T* a = un + base;  const T* b = vn + base;
+    const T* a1 = un1 + base; const T* b1 = vn1 + base;
+    T* out = (is_v ? vi : ui) + base;
+    T* ft = work + ((size_t)blockIdx.z * 2 + (is_v ? 1 : 0)) * nx * ny;     // ut / vt
+    const bool active = j < ny;
+    const bool edge_col = active && (j == 0 || j == ny - 1);
+    const bool solve = active && !edge_col;
+    const T two = (T)2, three = (T)3;
+    const T lo = -k.dt, up = -k.dt;
+
+    if (edge_col) {                                 // ui = u.copy() on the untouched columns
+        for (int i = 0; i < nx; ++i) out[(size_t)i * ny + j] = f[(size_t)i * ny + j];
+    }
+    // ---- first solve: A ut = (2/nu dx^2) (dt/2 (3H - H1) + dt nu lap f)        (:126-137)
+    T cp = k.a_diag, yprev = 0;
+    for (int i = 1; i <= nx - 2; ++i) {
+        T l = 0;
+        if (i > 1) { l = lo / cp; cp = k.a_diag - l * up; }
+        if (threadIdx.x == 0) cpA[i] = cp;
+        if (solve) {
+            const size_t c = (size_t)i * ny + j;
+            const T fc = f[c], fe = f[c + ny], fw = f[c - ny], fn = f[c + 1], fs = f[c - 1];
+            const T H = a[c] * (fe - fw) / k.two_dx + b[c] * (fn - fs) / k.two_dy;
+            const T H1 = a1[c] * (f1[c + ny] - f1[c - ny]) / k.two_dx + b1[c] * (f1[c + 1] - f1[c - 1]) / k.two_dy;
+            const T C1 = k.half_dt * (three * H - H1);
+            const T C2 = k.dt_nu * ((fe - two * fc + fw) / k.dx2 + (fn - two * fc + fs) / k.dy2);
+            const T rhs = k.cx * (C1 + C2);
+            const T y = i > 1 ? rhs - l * yprev : rhs;
+            ft[c] = y;
+            yprev = y;
+        }
+    }
+    __syncthreads();
+    if (solve) {
+        T xnext = 0;
+        for (int i = nx - 2; i >= 1; --i) {
+            const size_t c = (size_t)i * ny + j;
+            const T y = ft[c];
+            const T x = i == nx - 2 ? y / cpA[i] : (y - up * xnext) / cpA[i];
+            ft[c] = x;
+            xnext = x;
+        }
+    }
+    // ---- second solve: B ui = (2/nu dy^2)(ft + f) - dt d_yy f, again along axis 0   (:157-165)
+    cp = k.b_diag; yprev = 0;
+    for (int i = 1; i <= nx - 2; ++i) {
+        T l = 0;
+        if (i > 1) { l = lo / cp; cp = k.b_diag - l * up; }
+        if (threadIdx.x == 0) cpB[i] = cp;
+        if (solve) {
+            const size_t c = (size_t)i * ny + j;
+            const T fc = f[c];
+            const T rhs = k.cy * (ft[c] + fc) - k.dt * (f[c + 1] - two * fc + f[c - 1]);
+            const T y = i > 1 ? rhs - l * yprev : rhs;
+            out[c] = y;
+            yprev = y;
+        }
+    }
+    __syncthreads();
+    if (solve) {
+        T xnext = 0;
+        for (int i = nx - 2; i >= 1; --i) {
+            const size_t c = (size_t)i * ny + j;
+            const T y = out[c];
+            const T x = i == nx - 2 ? y / cpB[i] : (y - up * xnext) / cpB[i];
+            out[c] = x;
+            xnext = x;
+        }
+        out[j] = f[j];                                                  // rows 0 and nx-1 copied
+        out[(size_t)(nx - 1) * ny + j] = f[(size_t)(nx - 1) * ny + j];
+    }
+}
+
+template <typename T>
+int predictor_adi(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T* vi, T* work, int batch, int nx, int ny,
+                  double dt, double dx, double dy, double nu, hipStream_t s) {
+    if (!un || !vn || !un1 || !vn1 || !ui || !vi || !work || !field_args_ok(batch, nx, ny))
+        return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
+    if (nx != ny) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: the reference's second ADI solve acts along axis 0 (src/chorin_fd/simulate.py:159), which needs nx == ny (got %d x %d)", nx, ny);
+    if (nu == 0) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: nu must be non-zero (2/nu)");
+    AdiK<T> k;
+    k.dt = (T)dt; k.two_dx = (T)(2 * dx); k.two_dy = (T)(2 * dy); k.dx2 = (T)(dx * dx); k.dy2 = (T)(dy * dy);
+    k.dt_nu = (T)(dt * nu); k.half_dt = (T)(dt / 2.);
+    k.cx = (T)(2 / nu * (dx * dx)); k.cy = (T)(2 / nu * (dy * dy));         // (2/nu)*dx^2  (:134, :157)
+    k.a_diag = (T)(2 / nu * (dx * dx) + 2 * dt); k.b_diag = (T)(2 / nu * (dy * dy) + 2 * dt);   // :108, :117
+    const int tpb = 64;
+    const size_t shmem = 2 * (size_t)nx * sizeof(T);
+    if (shmem > 64 * 1024) return fail(NNS_ERR_UNSUPPORTED, "fd_predictor_adi: nx=%d too large for the LDS diagonal cache", nx);
+    hipLaunchKernelGGL(predictor_adi_kernel<T>, dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
+                       un, vn, un1, vn1, ui, vi, work, nx, ny, k);
+    return check_launch("fd_predictor_adi");
+}
+
+// ------------------------------------------------------------------------------------------
+// chorin_fd._get_pressure RHS (:186-188) and _correction_step (:204-210)
+// traffic: rhs 3T B/pt, correction 5T B/pt
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kTX) void pressure_rhs_kernel(const T* __restrict__ ui, const T* __restrict__ vi, T* __restrict__ C,
+                                                            int nx, int ny, T cu, T cv) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { C[c] = (T)0; return; }
+    C[c] = cu * (ui[c] - ui[c - ny]) + cv * (vi[c] - vi[c - 1]);
+}
+
+template <typename T>
+int pressure_rhs(const T* ui, const T* vi, T* C, int batch, int nx, int ny, double dt, double dx, double dy, double rho, hipStream_t s) {
+    if (!ui || !vi || !C || !field_args_ok(batch, nx, ny)) return fail(NNS_ERR_INVALID_ARG, "fd_pressure_rhs: bad args");
+    const T cu = (T)(dx * rho * (dy * dy) / dt), cv = (T)(dy * rho * (dx * dx) / dt);        // :187-188
+    hipLaunchKernelGGL(pressure_rhs_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, ui, vi, C, nx, ny, cu, cv);
+    return check_launch("fd_pressure_rhs");
+}
+
+template <typename T>
+__global__ __launch_bounds__(kTX) void correction_kernel(const T* __restrict__ ui, const T* __restrict__ vi, const T* __restrict__ p,
+                                                          T* __restrict__ u, T* __restrict__ v, int nx, int ny, T cx, T cy) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
+    const T uc = ui[c], vc = vi[c];
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { u[c] = uc; v[c] = vc; return; }
+    u[c] = uc - cx * (p[c + ny] - p[c - ny]);
+    v[c] = vc - cy * (p[c + 1] - p[c - 1]);
+}
+
+template <typename T>
+int correction(const T* ui, const T* vi, const T* p, T* u, T* v, int batch, int nx, int ny, double dt, double dx, double dy, hipStream_t s) {
+    if (!ui || !vi || !p || !u || !v || !field_args_ok(batch, nx, ny)) return fail(NNS_ERR_INVALID_ARG, "fd_correction: bad args");
+    hipLaunchKernelGGL(correction_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, ui, vi, p, u, v, nx, ny,
+                       (T)(dt / (2 * dx)), (T)(dt / (2 * dy)));
+    return check_launch("fd_correction");
+}
+
+// ------------------------------------------------------------------------------------------
+// direct_fd  (src/direct_fd/simulate.py; axis 1 = x, axis 0 = y)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kTX) void build_b_kernel(const T* __restrict__ u, const T* __restrict__ v, T* __restrict__ b,
+                                                       int nx, int ny, T rho, T inv_dt, T two_dx, T two_dy) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { b[c] = (T)0; return; }
+    const T ux = (u[c + 1] - u[c - 1]) / two_dx;        // d u / dx  (:60)
+    const T vy = (v[c + ny] - v[c - ny]) / two_dy;      // d v / dy  (:61)
+    const T uy = (u[c + ny] - u[c - ny]) / two_dy;      // :63
+    const T vx_num = (v[c + 1] - v[c - 1]);             // :64   (uy * vx_num) / two_dx keeps the reference order
+    b[c] = (rho * (inv_dt * (ux + vy)) - ux * ux - (T)2 * (uy * vx_num / two_dx) - vy * vy);
+}
+
+template <typename T>
+int build_b(const T* u, const T* v, T* b, int batch, int nx, int ny, double dt, double dx, double dy, double rho, hipStream_t s) {
+    if (!u || !v || !b || !field_args_ok(batch, nx, ny)) return fail(NNS_ERR_INVALID_ARG, "fd_build_b: bad args");
+    hipLaunchKernelGGL(build_b_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, u, v, b, nx, ny, (T)rho, (T)(1 / dt), (T)(2 * dx), (T)(2 * dy));
+    return check_launch("fd_build_b");
+}
+
+template <typename T>
+struct JacK { T dx2, dy2, den, cb; };
+
+template <typename T>
+__device__ __forceinline__ T jacobi_point(T e, T w, T n, T s, T bb, const JacK<T>& k) {
+    // (((pn[j+1] + pn[j-1]) * dy^2 + (pn[i+1] + pn[i-1]) * dx^2) / (2 (dx^2+dy^2)) - cb * b   (:78-82)
+    return ((e + w) * k.dy2 + (n + s) * k.dx2) / k.den - k.cb * bb;
+}
+
+// Multi-launch path (large grids): one sweep src -> dst, edges copied.  traffic 3T B/pt/sweep.
+template <typename T>
+__global__ __launch_bounds__(kTX) void jacobi_sweep_kernel(const T* __restrict__ src, T* __restrict__ dst, const T* __restrict__ b,
+                                                            int nx, int ny, JacK<T> k) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { dst[c] = src[c]; return; }
+    dst[c] = jacobi_point<T>(src[c + 1], src[c - 1], src[c + ny], src[c - ny], b[c], k);
+}
+
+// LDS-resident path (grids that fit): one workgroup per grid runs all nit sweeps, the BC list
+// after each, without leaving the CU.  HBM traffic 3T B/pt for the whole solve.
+template <typename T>
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(T* __restrict__ p, const T* __restrict__ b, int nx, int ny, int nit,
+                                                           JacK<T> k, BcListDev<T> bcs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = nx * ny;
+    T* buf0 = reinterpret_cast<T*>(smem_raw);
+    T* buf1 = buf0 + n;
+    T* bl = buf1 + n;
+    T* g = p + (size_t)blockIdx.x * n;
+    const T* bg = b + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int c = tid; c < n; c += nt) { const T v = g[c]; buf0[c] = v; buf1[c] = v; bl[c] = bg[c]; }
+    __syncthreads();
+    T* cur = buf0; T* nxt = buf1;
+    const int mi = nx - 2, mj = ny - 2;
+    for (int q = 0; q < nit; ++q) {
+        for (int t = tid; t < mi * mj; t += nt) {
+            const int i = 1 + t / mj, j = 1 + t % mj, c = i * ny + j;
+            nxt[c] = jacobi_point<T>(cur[c + 1], cur[c - 1], cur[c + ny], cur[c - ny], bl[c], k);
+        }
+        // edges of nxt still hold the values after the previous BC application (p is updated in
+        // place in the reference): copy them forward from cur before applying the BCs.
+        for (int t = tid; t < 2 * (nx + ny); t += nt) {
+            int i, j;
+            if (t < ny) { i = 0; j = t; } else if (t < 2 * ny) { i = nx - 1; j = t - ny; }
+            else if (t < 2 * ny + nx) { i = t - 2 * ny; j = 0; } else { i = t - 2 * ny - nx; j = ny - 1; }
+            nxt[i * ny + j] = cur[i * ny + j];
+        }
+        __syncthreads();
+        bc_apply_list<T>(nxt, nx, ny, bcs, tid, nt);
+        if (bcs.n == 0) __syncthreads();
+        T* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    for (int c = tid; c < n; c += nt) g[c] = cur[c];
+}
+
+template <typename T>
+int jacobi(T* p, T* tmp, const T* b, int batch, int nx, int ny, double dx, double dy, int nit, const nns_bc_list* h, hipStream_t s) {
+    if (!p || !b || !field_args_ok(batch, nx, ny) || nit < 0) return fail(NNS_ERR_INVALID_ARG, "fd_jacobi: bad args");
+    BcListDev<T> d;
+    if (int rc = make_bc_dev<T>(h, d)) return rc;
+    if (nit == 0) return NNS_OK;
+    JacK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx + dy * dy)), (T)((dx * dx) * (dy * dy) / (2 * (dx * dx + dy * dy)))};
+    const size_t lds = 3 * (size_t)nx * ny * sizeof(T);
+    if (lds <= 150 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_jacobi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(jacobi_lds_kernel<T>, dim3(batch), dim3(1024), lds, s, p, b, nx, ny, nit, k, d);
+        return check_launch("fd_jacobi(lds)");
+    }
+    if (!tmp) return fail(NNS_ERR_INVALID_ARG, "fd_jacobi: tmp scratch field required for %dx%d grids", nx, ny);
+    T* src = p; T* dst = tmp;
+    for (int q = 0; q < nit; ++q) {
+        hipLaunchKernelGGL(jacobi_sweep_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, src, dst, b, nx, ny, k);
+        if (d.n) hipLaunchKernelGGL(bc_apply_kernel<T>, dim3(batch), dim3(256), 0, s, dst, nx, ny, d);
+        T* t = src; src = dst; dst = t;
+    }
+    if (src != p) {
+        hipError_t e = hipMemcpyAsync(p, src, (size_t)batch * nx * ny * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_jacobi: copy-back: %s", hipGetErrorString(e));
+    }
+    return check_launch("fd_jacobi");
+}
+
+template <typename T>
+struct DirK { T dt, dx, dy, c_px, c_py, nu, dt_dx2, dt_dy2; };
+
+// direct_fd.step momentum update (:98-118).  traffic: read un,vn,p + write u,v = 5T B/pt
+template <typename T>
+__global__ __launch_bounds__(kTX) void direct_update_kernel(const T* __restrict__ un, const T* __restrict__ vn, const T* __restrict__ p,
+                                                             T* __restrict__ u, T* __restrict__ v, int nx, int ny, DirK<T> k) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
+    const T uc = un[c], vc = vn[c];
+    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { u[c] = uc; v[c] = vc; return; }
+    const T two = (T)2;
+    {
+        const T e = un[c + 1], w = un[c - 1], n = un[c + ny], s = un[c - ny];
+        u[c] = (uc - uc * k.dt / k.dx * (uc - w) - vc * k.dt / k.dy * (uc - s) - k.c_px * (p[c + 1] - p[c - 1]) +
+                k.nu * (k.dt_dx2 * (e - two * uc + w) + k.dt_dy2 * (n - two * uc + s)));
+    }
+    {
+        const T e = vn[c + 1], w = vn[c - 1], n = vn[c + ny], s = vn[c - ny];
+        v[c] = (vc - uc * k.dt / k.dx * (vc - w) - vc * k.dt / k.dy * (vc - s) - k.c_py * (p[c + ny] - p[c - ny]) +
+                k.nu * (k.dt_dx2 * (e - two * vc + w) + k.dt_dy2 * (n - two * vc + s)));
+    }
+}
+
+template <typename T>
+int direct_update(const T* un, const T* vn, const T* p, T* u, T* v, int batch, int nx, int ny, double dt, double dx, double dy,
+                  double rho, double nu, hipStream_t s) {
+    if (!un || !vn || !p || !u || !v || !field_args_ok(batch, nx, ny)) return fail(NNS_ERR_INVALID_ARG, "fd_direct_update: bad args");
+    if (un == u || vn == v) return fail(NNS_ERR_INVALID_ARG, "fd_direct_update: in/out must not alias");
+    DirK<T> k{(T)dt, (T)dx, (T)dy, (T)(dt / (2 * rho * dx)), (T)(dt / (2 * rho * dy)), (T)nu, (T)(dt / (dx * dx)), (T)(dt / (dy * dy))};
+    hipLaunchKernelGGL(direct_update_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, p, u, v, nx, ny, k);
+    return check_launch("fd_direct_update");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- C ABI
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+NNS_API int nns_bc_apply_f32(float* A, int batch, int nx, int ny, const nns_bc_list* bcs, void* stream) { return bc_apply<float>(A, batch, nx, ny, bcs, S(stream)); }
+NNS_API int nns_bc_apply_f64(double* A, int batch, int nx, int ny, const nns_bc_list* bcs, void* stream) { return bc_apply<double>(A, batch, nx, ny, bcs, S(stream)); }
+
+NNS_API int nns_fd_predictor_explicit_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi,
+                                          int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_explicit<float>(un, vn, un1, vn1, ui, vi, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+NNS_API int nns_fd_predictor_explicit_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi,
+                                          int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_explicit<double>(un, vn, un1, vn1, ui, vi, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+
+NNS_API size_t nns_fd_predictor_adi_workspace(int batch, int nx, int ny, int elem_size) {
+    if (batch < 1 || nx < 3 || ny < 3 || (elem_size != 4 && elem_size != 8)) return 0;
+    return (size_t)4 * batch * nx * ny * elem_size;
+}
+NNS_API int nns_fd_predictor_adi_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi, float* work,
+                                     int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_adi<float>(un, vn, un1, vn1, ui, vi, work, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+NNS_API int nns_fd_predictor_adi_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi, double* work,
+                                     int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_adi<double>(un, vn, un1, vn1, ui, vi, work, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+
+NNS_API int nns_fd_pressure_rhs_f32(const float* ui, const float* vi, float* C, int batch, int nx, int ny, double dt, double dx, double dy, double rho, void* stream) {
+    return pressure_rhs<float>(ui, vi, C, batch, nx, ny, dt, dx, dy, rho, S(stream));
+}
+NNS_API int nns_fd_pressure_rhs_f64(const double* ui, const double* vi, double* C, int batch, int nx, int ny, double dt, double dx, double dy, double rho, void* stream) {
+    return pressure_rhs<double>(ui, vi, C, batch, nx, ny, dt, dx, dy, rho, S(stream));
+}
+
+NNS_API int nns_fd_correction_f32(const float* ui, const float* vi, const float* p, float* u, float* v, int batch, int nx, int ny, double dt, double dx, double dy, void* stream) {
+    return correction<float>(ui, vi, p, u, v, batch, nx, ny, dt, dx, dy, S(stream));
+}
+NNS_API int nns_fd_correction_f64(const double* ui, const double* vi, const double* p, double* u, double* v, int batch, int nx, int ny, double dt, double dx, double dy, void* stream) {
+    return correction<double>(ui, vi, p, u, v, batch, nx, ny, dt, dx, dy, S(stream));
+}
+
+NNS_API int nns_fd_build_b_f32(const float* u, const float* v, float* b, int batch, int nx, int ny, double dt, double dx, double dy, double rho, void* stream) {
+    return build_b<float>(u, v, b, batch, nx, ny, dt, dx, dy, rho, S(stream));
+}
+NNS_API int nns_fd_build_b_f64(const double* u, const double* v, double* b, int batch, int nx, int ny, double dt, double dx, double dy, double rho, void* stream) {
+    return build_b<double>(u, v, b, batch, nx, ny, dt, dx, dy, rho, S(stream));
+}
+
+NNS_API int nns_fd_jacobi_f32(float* p, float* tmp, const float* b, int batch, int nx, int ny, double dx, double dy, int nit, const nns_bc_list* bc, void* stream) {
+    return jacobi<float>(p, tmp, b, batch, nx, ny, dx, dy, nit, bc, S(stream));
+}
+NNS_API int nns_fd_jacobi_f64(double* p, double* tmp, const double* b, int batch, int nx, int ny, double dx, double dy, int nit, const nns_bc_list* bc, void* stream) {
+    return jacobi<double>(p, tmp, b, batch, nx, ny, dx, dy, nit, bc, S(stream));
+}
+
+NNS_API int nns_fd_direct_update_f32(const float* un, const float* vn, const float* p, float* u, float* v, int batch, int nx, int ny,
+                                     double dt, double dx, double dy, double rho, double nu, void* stream) {
+    return direct_update<float>(un, vn, p, u, v, batch, nx, ny, dt, dx, dy, rho, nu, S(stream));
+}
+NNS_API int nns_fd_direct_update_f64(const double* un, const double* vn, const double* p, double* u, double* v, int batch, int nx, int ny,
+                                     double dt, double dx, double dy, double rho, double nu, void* stream) {
+    return direct_update<double>(un, vn, p, u, v, batch, nx, ny, dt, dx, dy, rho, nu, S(stream));
+}

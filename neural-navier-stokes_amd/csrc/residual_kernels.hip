@@ -1,0 +1,217 @@
+// Periodic-box Navier-Stokes residual, finite-difference back-end (5- and 9-point), gfx950.
+// Operator definition: oracle/periodic.py (no reference symbol exists).
+//
+//   r_u = (u-u_prev)/dt + u u_x + v u_y + p_x/rho - nu lap u,  r_v likewise,  r_div = u_x + v_y
+//
+// HBM-bound: compulsory traffic is 5 fields in + 3 out = 8T B/pt (32 B/pt in fp32) against
+// ~60 FLOP/pt.  Design for that bound:
+//   * every global access is a 16-byte vector per lane (float4 / double2), a wave moves 1 KiB
+//     contiguous per instruction;
+//   * a workgroup owns a band of R rows x (256 lanes x V columns) and MARCHES down the rows
+//     keeping rows i-1, i, i+1 of u, v, p in registers (rolling window): each input row is
+//     loaded once per band, halo overhead (R+2)/R on 3 of the 8 streams;
+//   * the j+-1 neighbours come from the adjacent lane by cross-lane shuffle, only the two edge
+//     lanes of a wave issue a (predicated) scalar load; periodic wrap is index arithmetic;
+//   * bands of one grid are laid out so that consecutive bands run on the same XCD (xcd_remap):
+//     the two halo rows of a band are L2 hits in that XCD, not extra HBM reads;
+//   * R is chosen on the host so that the launch has >= ~2048 workgroups when the problem
+//     allows (256 CUs x 8 resident blocks).
+#include "nns_common.h"
+
+using namespace nns;
+
+namespace {
+
+template <typename T> struct VecT;
+template <> struct VecT<float> { using type = float4; static constexpr int V = 4; };
+template <> struct VecT<double> { using type = double2; static constexpr int V = 2; };
+
+template <typename T>
+struct ResK { T inv_dt, inv_2dx, inv_2dy, inv_dx2, inv_dy2, inv_rho, nu, c9; };
+
+template <typename T>
+inline ResK<T> make_resk(double dt, double dx, double dy, double rho, double nu) {
+    ResK<T> k;
+    k.inv_dt = (T)(1.0 / dt); k.inv_2dx = (T)(1.0 / (2 * dx)); k.inv_2dy = (T)(1.0 / (2 * dy));
+    k.inv_dx2 = (T)(1.0 / (dx * dx)); k.inv_dy2 = (T)(1.0 / (dy * dy)); k.inv_rho = (T)(1.0 / rho); k.nu = (T)nu;
+    k.c9 = (T)((dx * dx + dy * dy) / 12.0 / (dx * dx * dy * dy));
+    return k;
+}
+
+template <typename T, int V>
+struct Row { T v[V]; T l, r; };          // V consecutive columns of one row + the two neighbours
+
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, T (&out)[VecT<T>::V]) {
+    using VT = typename VecT<T>::type;
+    const VT t = *reinterpret_cast<const VT*>(p);
+    if constexpr (VecT<T>::V == 4) { out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
+    else { out[0] = t.x; out[1] = t.y; }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const T (&in)[VecT<T>::V]) {
+    using VT = typename VecT<T>::type;
+    VT t;
+    if constexpr (VecT<T>::V == 4) { t.x = in[0]; t.y = in[1]; t.z = in[2]; t.w = in[3]; }
+    else { t.x = in[0]; t.y = in[1]; }
+    *reinterpret_cast<VT*>(p) = t;
+}
+
+// One row of one field: the lane's vector, plus left/right neighbours taken from the adjacent
+// lanes; lanes whose neighbour lives in another wave (or wraps around the box) load it.
+template <typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ rowp, int j0, int jl, int jr, bool need_l, bool need_r,
+                                         Row<T, VecT<T>::V>& R) {
+    constexpr int V = VecT<T>::V;
+    load_vec<T>(rowp + j0, R.v);
+    T l = __shfl_up(R.v[V - 1], 1);
+    T r = __shfl_down(R.v[0], 1);
+    if (need_l) l = rowp[jl];
+    if (need_r) r = rowp[jr];
+    R.l = l; R.r = r;
+}
+
+template <typename T, int STENCIL>
+__global__ __launch_bounds__(256) void fd_residual_vec_kernel(const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ p,
+                                                               const T* __restrict__ up, const T* __restrict__ vp,
+                                                               T* __restrict__ ru, T* __restrict__ rv, T* __restrict__ rd,
+                                                               int nx, int ny, int R, int nbands, int nstrips, ResK<T> k) {
+    constexpr int V = VecT<T>::V;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = lb % nstrips, band = (lb / nstrips) % nbands, b = lb / (nstrips * nbands);
+    const int nvec = ny / V;
+    const int jv_raw = strip * 256 + (int)threadIdx.x;
+    const bool valid = jv_raw < nvec;
+    const int jv = valid ? jv_raw : nvec - 1;
+    const int j0 = jv * V;
+    const int jl = j0 == 0 ? ny - 1 : j0 - 1;
+    const int jr = j0 + V == ny ? 0 : j0 + V;
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool need_l = lane == 0;
+    const bool need_r = lane == kWave - 1 || jv_raw >= nvec - 1;
+    const size_t g = (size_t)b * nx * ny;
+    const T* ug = u + g; const T* vg = v + g; const T* pg = p + g;
+    const int i0 = band * R, i1 = min(nx, i0 + R);
+    if (i0 >= nx) return;
+
+    Row<T, V> um, uc, un, vm, vc, vn, pm, pc, pn;
+    {
+        const size_t rm = (size_t)(i0 == 0 ? nx - 1 : i0 - 1) * ny, rc = (size_t)i0 * ny;
+        load_row<T>(ug + rm, j0, jl, jr, need_l, need_r, um); load_row<T>(ug + rc, j0, jl, jr, need_l, need_r, uc);
+        load_row<T>(vg + rm, j0, jl, jr, need_l, need_r, vm); load_row<T>(vg + rc, j0, jl, jr, need_l, need_r, vc);
+        load_row<T>(pg + rm, j0, jl, jr, need_l, need_r, pm); load_row<T>(pg + rc, j0, jl, jr, need_l, need_r, pc);
+    }
+    for (int i = i0; i < i1; ++i) {
+        const size_t rn = (size_t)(i + 1 == nx ? 0 : i + 1) * ny, rc = g + (size_t)i * ny + j0;
+        load_row<T>(ug + rn, j0, jl, jr, need_l, need_r, un);
+        load_row<T>(vg + rn, j0, jl, jr, need_l, need_r, vn);
+        load_row<T>(pg + rn, j0, jl, jr, need_l, need_r, pn);
+        T upv[V], vpv[V], o_u[V], o_v[V], o_d[V];
+        load_vec<T>(up + rc, upv);
+        load_vec<T>(vp + rc, vpv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T ucc = uc.v[e], vcc = vc.v[e];
+            const T ul = e == 0 ? uc.l : uc.v[e > 0 ? e - 1 : 0], ur = e == V - 1 ? uc.r : uc.v[e < V - 1 ? e + 1 : 0];
+            const T vl = e == 0 ? vc.l : vc.v[e > 0 ? e - 1 : 0], vr = e == V - 1 ? vc.r : vc.v[e < V - 1 ? e + 1 : 0];
+            const T pl = e == 0 ? pc.l : pc.v[e > 0 ? e - 1 : 0], pr = e == V - 1 ? pc.r : pc.v[e < V - 1 ? e + 1 : 0];
+            const T ux = (un.v[e] - um.v[e]) * k.inv_2dx, uy = (ur - ul) * k.inv_2dy;
+            const T vx = (vn.v[e] - vm.v[e]) * k.inv_2dx, vy = (vr - vl) * k.inv_2dy;
+            const T px = (pn.v[e] - pm.v[e]) * k.inv_2dx, py = (pr - pl) * k.inv_2dy;
+            T lu = (un.v[e] - 2 * ucc + um.v[e]) * k.inv_dx2 + (ur - 2 * ucc + ul) * k.inv_dy2;
+            T lv = (vn.v[e] - 2 * vcc + vm.v[e]) * k.inv_dx2 + (vr - 2 * vcc + vl) * k.inv_dy2;
+            if constexpr (STENCIL == 9) {
+                const T uml = e == 0 ? um.l : um.v[e > 0 ? e - 1 : 0], umr = e == V - 1 ? um.r : um.v[e < V - 1 ? e + 1 : 0];
+                const T unl = e == 0 ? un.l : un.v[e > 0 ? e - 1 : 0], unr = e == V - 1 ? un.r : un.v[e < V - 1 ? e + 1 : 0];
+                const T vml = e == 0 ? vm.l : vm.v[e > 0 ? e - 1 : 0], vmr = e == V - 1 ? vm.r : vm.v[e < V - 1 ? e + 1 : 0];
+                const T vnl = e == 0 ? vn.l : vn.v[e > 0 ? e - 1 : 0], vnr = e == V - 1 ? vn.r : vn.v[e < V - 1 ? e + 1 : 0];
+                lu += k.c9 * ((uml + umr + unl + unr) - 2 * (um.v[e] + un.v[e] + ul + ur) + 4 * ucc);
+                lv += k.c9 * ((vml + vmr + vnl + vnr) - 2 * (vm.v[e] + vn.v[e] + vl + vr) + 4 * vcc);
+            }
+            o_u[e] = (ucc - upv[e]) * k.inv_dt + ucc * ux + vcc * uy + px * k.inv_rho - k.nu * lu;
+            o_v[e] = (vcc - vpv[e]) * k.inv_dt + ucc * vx + vcc * vy + py * k.inv_rho - k.nu * lv;
+            o_d[e] = ux + vy;
+        }
+        if (valid) { store_vec<T>(ru + rc, o_u); store_vec<T>(rv + rc, o_v); store_vec<T>(rd + rc, o_d); }
+        um = uc; uc = un; vm = vc; vc = vn; pm = pc; pc = pn;
+    }
+}
+
+// Any-size fallback (ny not a multiple of the vector width): one thread per point.
+template <typename T, int STENCIL>
+__global__ __launch_bounds__(256) void fd_residual_generic_kernel(const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ p,
+                                                                   const T* __restrict__ up, const T* __restrict__ vp,
+                                                                   T* __restrict__ ru, T* __restrict__ rv, T* __restrict__ rd,
+                                                                   int nx, int ny, ResK<T> k) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t g = (size_t)blockIdx.z * nx * ny;
+    const int im = i == 0 ? nx - 1 : i - 1, in = i + 1 == nx ? 0 : i + 1;
+    const int jm = j == 0 ? ny - 1 : j - 1, jn = j + 1 == ny ? 0 : j + 1;
+    auto at = [&](const T* f, int a, int b) { return f[g + (size_t)a * ny + b]; };
+    const T ucc = at(u, i, j), vcc = at(v, i, j);
+    const T ue = at(u, in, j), uw = at(u, im, j), ur = at(u, i, jn), ul = at(u, i, jm);
+    const T ve = at(v, in, j), vw = at(v, im, j), vr = at(v, i, jn), vl = at(v, i, jm);
+    const T ux = (ue - uw) * k.inv_2dx, uy = (ur - ul) * k.inv_2dy;
+    const T vx = (ve - vw) * k.inv_2dx, vy = (vr - vl) * k.inv_2dy;
+    const T px = (at(p, in, j) - at(p, im, j)) * k.inv_2dx, py = (at(p, i, jn) - at(p, i, jm)) * k.inv_2dy;
+    T lu = (ue - 2 * ucc + uw) * k.inv_dx2 + (ur - 2 * ucc + ul) * k.inv_dy2;
+    T lv = (ve - 2 * vcc + vw) * k.inv_dx2 + (vr - 2 * vcc + vl) * k.inv_dy2;
+    if constexpr (STENCIL == 9) {
+        lu += k.c9 * ((at(u, im, jm) + at(u, im, jn) + at(u, in, jm) + at(u, in, jn)) - 2 * (uw + ue + ul + ur) + 4 * ucc);
+        lv += k.c9 * ((at(v, im, jm) + at(v, im, jn) + at(v, in, jm) + at(v, in, jn)) - 2 * (vw + ve + vl + vr) + 4 * vcc);
+    }
+    const size_t c = g + (size_t)i * ny + j;
+    ru[c] = (ucc - up[c]) * k.inv_dt + ucc * ux + vcc * uy + px * k.inv_rho - k.nu * lu;
+    rv[c] = (vcc - vp[c]) * k.inv_dt + ucc * vx + vcc * vy + py * k.inv_rho - k.nu * lv;
+    rd[c] = ux + vy;
+}
+
+template <typename T>
+int fd_residual(const T* u, const T* v, const T* p, const T* up, const T* vp, T* ru, T* rv, T* rd, int batch, int nx, int ny,
+                double dt, double dx, double dy, double rho, double nu, int stencil, hipStream_t s) {
+    if (!u || !v || !p || !up || !vp || !ru || !rv || !rd || !field_args_ok(batch, nx, ny))
+        return fail(NNS_ERR_INVALID_ARG, "fd_residual: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
+    if (stencil != 5 && stencil != 9) return fail(NNS_ERR_INVALID_ARG, "fd_residual: stencil must be 5 or 9 (got %d)", stencil);
+    if (dt == 0 || dx == 0 || dy == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "fd_residual: dt, dx, dy, rho must be non-zero");
+    const ResK<T> k = make_resk<T>(dt, dx, dy, rho, nu);
+    constexpr int V = VecT<T>::V;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(p) |
+                           reinterpret_cast<uintptr_t>(up) | reinterpret_cast<uintptr_t>(vp) | reinterpret_cast<uintptr_t>(ru) |
+                           reinterpret_cast<uintptr_t>(rv) | reinterpret_cast<uintptr_t>(rd)) & 15) == 0;
+    if (ny % V == 0 && ny >= 2 * V && aligned) {
+        const int nvec = ny / V, nstrips = (nvec + 255) / 256;
+        // rows per band: aim for >= 2048 workgroups, keep the halo overhead (R+2)/R small
+        long want = 2048;
+        int R = (int)(((long)batch * nx * nstrips + want - 1) / want);
+        R = R < 4 ? 4 : (R > 32 ? 32 : R);
+        const int nbands = (nx + R - 1) / R;
+        const long nblocks = (long)batch * nbands * nstrips;
+        if (nblocks > 0x7fffffffL) return fail(NNS_ERR_UNSUPPORTED, "fd_residual: grid too large");
+        if (stencil == 5)
+            hipLaunchKernelGGL((fd_residual_vec_kernel<T, 5>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, R, nbands, nstrips, k);
+        else
+            hipLaunchKernelGGL((fd_residual_vec_kernel<T, 9>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, R, nbands, nstrips, k);
+    } else {
+        const dim3 grid((ny + 255) / 256, nx, batch);
+        if (stencil == 5)
+            hipLaunchKernelGGL((fd_residual_generic_kernel<T, 5>), grid, dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, k);
+        else
+            hipLaunchKernelGGL((fd_residual_generic_kernel<T, 9>), grid, dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, k);
+    }
+    return check_launch("fd_residual");
+}
+
+}  // namespace
+
+NNS_API int nns_fd_residual_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                float* r_u, float* r_v, float* r_div, int batch, int nx, int ny, double dt, double dx, double dy,
+                                double rho, double nu, int stencil, void* stream) {
+    return fd_residual<float>(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_residual_f64(const double* u, const double* v, const double* p, const double* u_prev, const double* v_prev,
+                                double* r_u, double* r_v, double* r_div, int batch, int nx, int ny, double dt, double dx, double dy,
+                                double rho, double nu, int stencil, void* stream) {
+    return fd_residual<double>(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream));
+}

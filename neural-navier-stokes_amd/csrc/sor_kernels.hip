@@ -1,0 +1,146 @@
+// chorin_fd._get_pressure SOR loop (src/chorin_fd/simulate.py:190-200) on gfx950.
+//
+// The reference sweeps the interior in lexicographic order, IN PLACE (Gauss-Seidel + over-
+// relaxation).  Point (i,j) therefore sees (i-1,j),(i,j-1) of the current sweep and (i+1,j),
+// (i,j+1) of the previous one.  All points of an anti-diagonal d = i+j are independent and see
+// exactly those values if the diagonals are visited in increasing d: the wavefront order is
+// bitwise identical to the reference order (oracle/chorin_fd.py: sor_sweep_wavefront).
+//
+// One workgroup per grid (the solve is sequential across fronts: "replicas only" across GPUs).
+// Parallelism beyond one front comes from keeping several SWEEPS in flight: wave w runs sweep
+// s0+w, two fronts behind wave w-1 (the minimum lag for the in-place dependency, one workgroup
+// barrier per step), so a batch of W sweeps costs nfronts + 2(W-1) steps instead of W*nfronts.
+//
+// The data-dependent stop (first sweep with max|p - pPrev| <= tol, :190,:198) is kept exact:
+// every sweep records its own max update; if a sweep inside a batch meets the tolerance, the
+// grid is restored from the snapshot taken at the start of the batch and exactly that many
+// sweeps are replayed.  Compiled with -ffp-contract=off (reference operation order).
+#include "nns_common.h"
+
+using namespace nns;
+
+namespace {
+
+constexpr int kSorThreads = 1024;                 // 16 waves
+constexpr int kSorWaves = kSorThreads / kWave;
+constexpr int kSorHdr = 256;                       // LDS header: per-sweep errs + stop flag
+
+template <typename T>
+struct SorK { T dx2, dy2, den, beta, omb, tol; };
+
+template <typename T>
+__device__ __forceinline__ T nanmax(T a, T b) { return (b > a || b != b) ? b : a; }
+
+// Runs sweeps [0, nsw) pipelined on pw (LDS or global); errs[s] = max update of sweep s.
+template <typename T>
+__device__ __forceinline__ void sor_batch(T* pw, const T* cw, int nx, int ny, int nsw, const SorK<T>& k, T* errs) {
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int nfronts = nx + ny - 5;                       // d = 2 .. nx+ny-4
+    const int nsteps = nfronts + 2 * (nsw - 1);
+    T emax = (T)0;
+    for (int t = 0; t < nsteps; ++t) {
+        const int f = t - 2 * wave;
+        if (wave < nsw && f >= 0 && f < nfronts) {
+            const int d = f + 2;
+            const int ilo = max(1, d - (ny - 2)), ihi = min(nx - 2, d - 1);
+            for (int i = ilo + lane; i <= ihi; i += kWave) {
+                const int c = i * ny + (d - i);
+                const T old = pw[c];
+                const T nw = (k.beta * (k.dy2 * pw[c + ny] + k.dy2 * pw[c - ny] + k.dx2 * pw[c + 1] + k.dx2 * pw[c - 1] - cw[c]) / k.den +
+                              k.omb * old);                                           // :193-196
+                pw[c] = nw;
+                emax = nanmax<T>(emax, fabs(nw - old));
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = kWave / 2; o > 0; o >>= 1) emax = nanmax<T>(emax, __shfl_down(emax, o));
+    if (lane == 0 && wave < nsw) errs[wave] = emax;
+    __syncthreads();
+}
+
+template <typename T, bool IN_LDS>
+__global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, const T* __restrict__ C, T* __restrict__ info,
+                                                           T* __restrict__ snap, int nx, int ny, int max_sweeps, SorK<T> k) {
+    // all LDS in the dynamic region (16-byte aligned carve): [errs 16 x 8 B][stop][pad to 256][p][C]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* errs = reinterpret_cast<T*>(smem_raw);
+    int* s_stop_p = reinterpret_cast<int*>(smem_raw + 128);
+    const int n = nx * ny, tid = threadIdx.x;
+    T* pg = p + (size_t)blockIdx.x * n;
+    const T* cg = C + (size_t)blockIdx.x * n;
+    T* sg = snap + (size_t)blockIdx.x * n;
+    T* pw = pg;
+    const T* cw = cg;
+    if (IN_LDS) {
+        T* pl = reinterpret_cast<T*>(smem_raw + kSorHdr);
+        T* cl = pl + n;
+        for (int c = tid; c < n; c += kSorThreads) { pl[c] = pg[c]; cl[c] = cg[c]; }
+        pw = pl; cw = cl;
+        __syncthreads();
+    }
+    int done = 0;
+    T err = (T)1;                                                     // :183
+    while (done < max_sweeps) {
+        const int nsw = min(kSorWaves, max_sweeps - done);
+        for (int c = tid; c < n; c += kSorThreads) sg[c] = pw[c];      // snapshot for an exact early stop
+        __syncthreads();
+        sor_batch<T>(pw, cw, nx, ny, nsw, k, errs);
+        if (tid == 0) {
+            int stop = -1;
+            for (int s = 0; s < nsw; ++s) if (!(errs[s] > k.tol)) { stop = s; break; }    // loop runs while err > tol
+            *s_stop_p = stop;
+        }
+        __syncthreads();
+        const int stop = *s_stop_p;
+        if (stop < 0) { done += nsw; err = errs[nsw - 1]; __syncthreads(); continue; }
+        if (stop < nsw - 1) {                                          // overshoot: restore and replay stop+1 sweeps
+            const T e_keep = errs[stop];
+            __syncthreads();
+            for (int c = tid; c < n; c += kSorThreads) pw[c] = sg[c];
+            __syncthreads();
+            sor_batch<T>(pw, cw, nx, ny, stop + 1, k, errs);
+            err = e_keep;
+        } else {
+            err = errs[stop];
+        }
+        done += stop + 1;
+        break;
+    }
+    __syncthreads();
+    if (IN_LDS) for (int c = tid; c < n; c += kSorThreads) pg[c] = pw[c];
+    if (tid == 0) { info[2 * blockIdx.x] = (T)done; info[2 * blockIdx.x + 1] = err; }
+}
+
+template <typename T>
+int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double dx, double dy, double beta, double tol,
+        int max_sweeps, hipStream_t s) {
+    if (!p || !C || !info || !work || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
+        return fail(NNS_ERR_INVALID_ARG, "fd_sor: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
+    const size_t lds = kSorHdr + 2 * (size_t)nx * ny * sizeof(T);
+    T* snap = reinterpret_cast<T*>(work);
+    if (lds <= 150 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((sor_kernel<T, true>), dim3(batch), dim3(kSorThreads), lds, s, p, C, info, snap, nx, ny, max_sweeps, k);
+    } else {
+        hipLaunchKernelGGL((sor_kernel<T, false>), dim3(batch), dim3(kSorThreads), kSorHdr, s, p, C, info, snap, nx, ny, max_sweeps, k);
+    }
+    return check_launch("fd_sor");
+}
+
+}  // namespace
+
+NNS_API size_t nns_fd_sor_workspace(int batch, int nx, int ny, int elem_size) {
+    if (batch < 1 || nx < 3 || ny < 3 || (elem_size != 4 && elem_size != 8)) return 0;
+    return (size_t)batch * nx * ny * elem_size;
+}
+NNS_API int nns_fd_sor_f32(float* p, const float* C, float* info, void* work, int batch, int nx, int ny, double dx, double dy,
+                           double beta, double tol, int max_sweeps, void* stream) {
+    return sor<float>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny, double dx, double dy,
+                           double beta, double tol, int max_sweeps, void* stream) {
+    return sor<double>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,345 @@
+// Fourier-spectral back-end of the periodic Navier-Stokes residual, gfx950.
+// Operator definition: oracle/periodic.py (spectral_residual); no reference symbol exists
+// (SURVEY.md section 8 row a17).
+//
+// The derivative operators are separable (d/dx touches axis 0 only, d/dy axis 1 only, and the
+// Laplacian is their sum), so no 2-D transform is ever materialised in HBM:
+//
+//   x-pass (columns, axis 0):  P_u = u u_x + p_x/rho - nu u_xx,  P_v = u v_x - nu v_xx,  P_d = u_x
+//   y-pass (rows,    axis 1):  r_u = (u-u_prev)/dt + P_u + v u_y        - nu u_yy
+//                              r_v = (v-v_prev)/dt + P_v + v v_y + p_y/rho - nu v_yy
+//                              r_div = P_d + v_y
+//
+// Each pass runs 1-D FFTs that live entirely in registers + LDS (fft_lds.h).  Per line it needs
+// two forward and two inverse complex transforms, using linearity to pack real fields:
+//   Z1 = FFT(u + i v), Z2 = FFT(p)        A = i k Z1                 -> ifft = u' + i v'
+//                                         B = nu k^2 Z1 + (p-term)   -> ifft = L_u + i L_v
+// (a derivative is a real linear operator, so it acts on the real and imaginary part of a packed
+// signal independently; the Nyquist mode is dropped for odd derivatives, as in the oracle).
+//
+// Precision: with TF = double the forward transforms and the spectral multiply run in float64
+// and the inverse in float32.  Forward rounding noise is white in k and the multiply amplifies it
+// by k (k^2): all-float32 gives ~2e-4 rel-L2 at N = 1024, the mixed scheme 3e-7 (measured,
+// DESIGN.md).  TF = float is the opt-in fast mode.
+//
+// HBM traffic (fp32 fields): x-pass 3 in + 3 out = 24 B/pt, y-pass 8 in + 3 out = 44 B/pt.
+// Column access in the x-pass goes through an LDS transpose stage so that global accesses are
+// 32..128-byte row pieces (a workgroup owns 8*FPW adjacent columns), and tiles that share
+// 128-byte lines run on the same XCD (xcd_remap) so the line is fetched from HBM once.
+#include "nns_common.h"
+#include "fft_lds.h"
+#include <type_traits>
+
+using namespace nns;
+
+namespace {
+
+constexpr int kSpecThreads = 512;                  // 8 waves: 2 per SIMD, <= 256 VGPRs each
+constexpr int kSpecWaves = kSpecThreads / kWave;
+
+struct SpecK {
+    double kscale;        // 2 pi / L for the transformed axis
+    double inv_rho, nu, inv_n;
+    float inv_dt;
+};
+
+template <int N, typename TF>
+struct SpecLds {
+    static constexpr int TPF = N / 16;
+    static constexpr int FPW = kWave / TPF;                       // lines per wave
+    static constexpr int LINES = kSpecWaves * FPW;                // lines per workgroup
+    static constexpr int SLOTS = N + N / 16;
+    static constexpr int STAGE_F = N + 16;                        // floats per staged field (padded)
+    static constexpr int XB_BYTES = SLOTS * (int)sizeof(C2<TF>);
+    static constexpr int SKEW_MOD = LINES < 32 ? LINES : 32;           // staging skew: line%SKEW_MOD * SKEW_DW dwords,
+    static constexpr int SKEW_DW = 32 / SKEW_MOD;                       // so a 32-lane store group hits 32 banks
+    static constexpr int STAGE_BYTES = 3 * STAGE_F * 4 + 128;
+    static constexpr int LINE_BYTES = ((XB_BYTES > STAGE_BYTES ? XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
+    static constexpr int TABF_BYTES = (N / 2) * (int)sizeof(C2<TF>);
+    static constexpr int TABI_BYTES = sizeof(TF) == 4 ? 0 : (N / 2) * (int)sizeof(C2<float>);
+    static constexpr int TOTAL = TABF_BYTES + TABI_BYTES + LINES * LINE_BYTES;
+};
+
+// signed wavenumber index of element e: (odd-derivative k [Nyquist -> 0], k for even derivatives)
+template <int N>
+__device__ __forceinline__ void wavenumber(int e, int& k_odd, int& k_even) {
+    const int k = e < N / 2 ? e : e - N;
+    k_even = k;
+    k_odd = (e == N / 2) ? 0 : k;
+}
+
+// The shared core: from the line's u, v, p (element tid + TPF*m in slot m) produce
+//   a = (f_u', f_v')  and  b = (L_u, L_v)  with the pressure-gradient term added to the real part
+//   (P_IN_REAL, x-pass) or the imaginary part (y-pass) of b.
+template <int N, typename TF, bool P_IN_REAL>
+__device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&vf)[16], const float (&pf)[16],
+                                           C2<float> (&a)[16], C2<float> (&b)[16],
+                                           const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid,
+                                           const SpecK& k) {
+    constexpr int TPF = N / 16;
+    C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);
+    C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
+    C2<TF> z[16];
+    // ---- pressure: Z2 = FFT(p); keep only its contribution to b, already scaled, in float
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
+    fft_line<TF, N, false>(z, tabF, xbF, tid);
+    __builtin_amdgcn_sched_barrier(0);          // phases are independent: keep the scheduler from overlapping them
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        int ko, ke;
+        wavenumber<N>(tid + TPF * m, ko, ke);
+        const TF s = (TF)((double)ko * k.kscale * k.inv_rho * k.inv_n);
+        if constexpr (P_IN_REAL) { b[m].x = (float)(-s * z[m].y); b[m].y = (float)(s * z[m].x); }   // (i k/rho) Z2
+        else { b[m].x = (float)(-s * z[m].x); b[m].y = (float)(-s * z[m].y); }                       // i (i k/rho) Z2
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- velocity: Z1 = FFT(u + i v)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)uf[m]; z[m].y = (TF)vf[m]; }
+    fft_line<TF, N, false>(z, tabF, xbF, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        int ko, ke;
+        wavenumber<N>(tid + TPF * m, ko, ke);
+        const TF k1 = (TF)((double)ko * k.kscale * k.inv_n);
+        const double kk = (double)ke * k.kscale;
+        const TF k2 = (TF)(k.nu * kk * kk * k.inv_n);
+        a[m].x = (float)(-k1 * z[m].y); a[m].y = (float)(k1 * z[m].x);        // i k Z1
+        b[m].x += (float)(k2 * z[m].x); b[m].y += (float)(k2 * z[m].y);       // nu k^2 Z1
+    }
+    // ---- inverse transforms in float32
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true>(a, tabI, xbI, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true>(b, tabI, xbI, tid);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int N, typename TF>
+__device__ __forceinline__ void spec_setup(unsigned char* smem, C2<TF>*& tabF, C2<float>*& tabI, unsigned char*& lines) {
+    using L = SpecLds<N, TF>;
+    tabF = reinterpret_cast<C2<TF>*>(smem);
+    fill_twiddles<TF, N>(tabF, threadIdx.x, kSpecThreads);
+    if constexpr (sizeof(TF) == 4) {
+        tabI = reinterpret_cast<C2<float>*>(smem);
+    } else {
+        tabI = reinterpret_cast<C2<float>*>(smem + L::TABF_BYTES);
+        fill_twiddles<float, N>(tabI, threadIdx.x, kSpecThreads);
+    }
+    lines = smem + L::TABF_BYTES + L::TABI_BYTES;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// y-pass: rows (contiguous lines).  One line per TPF lanes; a workgroup iteration handles
+// LINES rows; grid-stride over all batch*nx rows.
+// ------------------------------------------------------------------------------------------
+template <int N, typename TF>
+__global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                   const float* __restrict__ p, const float* __restrict__ up,
+                                                                   const float* __restrict__ vp, float* __restrict__ ru,
+                                                                   float* __restrict__ rv, float* __restrict__ rd,
+                                                                   long nrows, SpecK k) {
+    using L = SpecLds<N, TF>;
+    constexpr int TPF = L::TPF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, TF>(smem, tabF, tabI, lines);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int sub = lane / TPF, tid = lane % TPF;
+    const int line = wave * L::FPW + sub;
+    unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
+    const long niter = (nrows + L::LINES - 1) / L::LINES;
+    for (long it = blockIdx.x; it < niter; it += gridDim.x) {
+        const long row_raw = it * L::LINES + line;
+        const bool valid = row_raw < nrows;
+        const long row = valid ? row_raw : nrows - 1;
+        // Per-lane loop invariants (wavenumber factors, twiddle reads) would be hoisted out of this loop
+        // by LICM and pinned in ~150 VGPRs for the whole body: make the lane id opaque per iteration.
+        int tidv = tid;
+        asm volatile("" : "+v"(tidv));
+        const size_t base = (size_t)row * N + tidv;
+        float uf[16], vf[16], pf[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { uf[m] = u[base + TPF * m]; vf[m] = v[base + TPF * m]; pf[m] = p[base + TPF * m]; }
+        C2<float> a[16], b[16];
+        deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k);
+        if (valid) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const size_t c = base + TPF * m;
+                const float uu = u[c], vv = v[c];                 // L2-hot re-read instead of 32 live VGPRs
+                ru[c] = (uu - up[c]) * k.inv_dt + ru[c] + vv * a[m].x + b[m].x;
+                rv[c] = (vv - vp[c]) * k.inv_dt + rv[c] + vv * a[m].y + b[m].y;
+                rd[c] = rd[c] + a[m].y;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// x-pass: columns.  A workgroup owns LINES adjacent columns of one grid; the tile is staged
+// through LDS so that global accesses are row pieces of LINES*4 bytes.
+// ------------------------------------------------------------------------------------------
+template <int N, typename TF>
+__global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                   const float* __restrict__ p, float* __restrict__ ru,
+                                                                   float* __restrict__ rv, float* __restrict__ rd,
+                                                                   int ny, int tiles_per_grid, long ntiles, SpecK k) {
+    using L = SpecLds<N, TF>;
+    constexpr int TPF = L::TPF, CW = L::LINES, SF = L::STAGE_F;
+    constexpr int ROWS_PER_IT = kSpecThreads / CW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, TF>(smem, tabF, tabI, lines);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int sub = lane / TPF, tid = lane % TPF;
+    const int line = wave * L::FPW + sub;
+    unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
+    float* my_stage = reinterpret_cast<float*>(xb) + (line % L::SKEW_MOD) * L::SKEW_DW;   // skewed: conflict-free staging
+    // cooperative-copy role of this thread: column cc of the tile, rows cr + ROWS_PER_IT*i
+    const int cc = threadIdx.x % CW, cr = threadIdx.x / CW;
+    float* cp_stage = reinterpret_cast<float*>(lines + (size_t)cc * L::LINE_BYTES) + (cc % L::SKEW_MOD) * L::SKEW_DW;
+
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long lt = xcd_remap((unsigned)t, (unsigned)ntiles);            // neighbouring tiles -> same XCD (shared lines)
+        const int b = (int)(lt / tiles_per_grid), tile = (int)(lt % tiles_per_grid);
+        const int j0 = tile * CW;
+        const size_t g = (size_t)b * N * ny;
+        const bool col_ok = j0 + cc < ny;
+        // ---- stage u, v, p columns: global row pieces -> LDS [line][field][row]
+        for (int r = cr; r < N; r += ROWS_PER_IT) {
+            const size_t c = g + (size_t)r * ny + j0 + cc;
+            cp_stage[0 * SF + r] = col_ok ? u[c] : 0.f;
+            cp_stage[1 * SF + r] = col_ok ? v[c] : 0.f;
+            cp_stage[2 * SF + r] = col_ok ? p[c] : 0.f;
+        }
+        __syncthreads();
+        int tidv = tid;                                  // opaque per iteration: see the y-pass
+        asm volatile("" : "+v"(tidv));
+        float uf[16], vf[16], pf[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            uf[m] = my_stage[0 * SF + tidv + TPF * m]; vf[m] = my_stage[1 * SF + tidv + TPF * m]; pf[m] = my_stage[2 * SF + tidv + TPF * m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        C2<float> a[16], b2[16];
+        deriv_core<N, TF, true>(uf, vf, pf, a, b2, tabF, tabI, xb, tidv, k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            my_stage[0 * SF + tidv + TPF * m] = uf[m] * a[m].x + b2[m].x;     // P_u = u u_x + p_x/rho - nu u_xx
+            my_stage[1 * SF + tidv + TPF * m] = uf[m] * a[m].y + b2[m].y;     // P_v = u v_x - nu v_xx
+            my_stage[2 * SF + tidv + TPF * m] = a[m].x;                       // P_d = u_x
+        }
+        __syncthreads();
+        if (col_ok) {
+            for (int r = cr; r < N; r += ROWS_PER_IT) {
+                const size_t c = g + (size_t)r * ny + j0 + cc;
+                ru[c] = cp_stage[0 * SF + r];
+                rv[c] = cp_stage[1 * SF + r];
+                rd[c] = cp_stage[2 * SF + r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int N, typename TF>
+int launch_xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int ny, const SpecK& k, hipStream_t s) {
+    using L = SpecLds<N, TF>;
+    const int tiles_per_grid = (ny + L::LINES - 1) / L::LINES;
+    const long ntiles = (long)batch * tiles_per_grid;
+    auto kern = spec_xpass_kernel<N, TF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec xpass: hipFuncSetAttribute(%d B): %s", L::TOTAL, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, ru, rv, rd, ny, tiles_per_grid, ntiles, k);
+    return check_launch("spec_residual_xpass");
+}
+
+template <int N, typename TF>
+int launch_ypass(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
+                 long nrows, const SpecK& k, hipStream_t s) {
+    using L = SpecLds<N, TF>;
+    auto kern = spec_ypass_kernel<N, TF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec ypass: hipFuncSetAttribute(%d B): %s", L::TOTAL, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long niter = (nrows + L::LINES - 1) / L::LINES;
+    const unsigned grid = (unsigned)(niter < 2048 ? niter : 2048);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, nrows, k);
+    return check_launch("spec_residual_ypass");
+}
+
+inline bool pow2_in_range(int n) { return n >= 64 && n <= 1024 && (n & (n - 1)) == 0; }
+
+template <typename F>
+int dispatch_n(int n, F&& f) {
+    switch (n) {
+        case 64: return f(std::integral_constant<int, 64>{});
+        case 128: return f(std::integral_constant<int, 128>{});
+        case 256: return f(std::integral_constant<int, 256>{});
+        case 512: return f(std::integral_constant<int, 512>{});
+        case 1024: return f(std::integral_constant<int, 1024>{});
+    }
+    return fail(NNS_ERR_UNSUPPORTED, "spectral: axis length %d is not a power of two in [64, 1024]", n);
+}
+
+int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
+          double Lx, double rho, double nu, int precise, hipStream_t s) {
+    if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
+    if (!pow2_in_range(nx)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_xpass: nx=%d must be a power of two in [64, 1024]", nx);
+    if (Lx == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: Lx, rho must be non-zero");
+    SpecK k{2.0 * M_PI / Lx, 1.0 / rho, nu, 1.0 / nx, 0.f};
+    return dispatch_n(nx, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        return precise ? launch_xpass<N, double>(u, v, p, ru, rv, rd, batch, ny, k, s)
+                       : launch_xpass<N, float>(u, v, p, ru, rv, rd, batch, ny, k, s);
+    });
+}
+
+int ypass(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
+          int batch, int nx, int ny, double dt, double Ly, double rho, double nu, int precise, hipStream_t s) {
+    if (!u || !v || !p || !up || !vp || !ru || !rv || !rd || batch < 1 || nx < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_ypass: bad args");
+    if (!pow2_in_range(ny)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_ypass: ny=%d must be a power of two in [64, 1024]", ny);
+    if (Ly == 0 || rho == 0 || dt == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_ypass: Ly, rho, dt must be non-zero");
+    SpecK k{2.0 * M_PI / Ly, 1.0 / rho, nu, 1.0 / ny, (float)(1.0 / dt)};
+    const long nrows = (long)batch * nx;
+    return dispatch_n(ny, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        return precise ? launch_ypass<N, double>(u, v, p, up, vp, ru, rv, rd, nrows, k, s)
+                       : launch_ypass<N, float>(u, v, p, up, vp, ru, rv, rd, nrows, k, s);
+    });
+}
+
+}  // namespace
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+NNS_API int nns_spec_residual_xpass_f32(const float* u, const float* v, const float* p, float* r_u, float* r_v, float* r_div,
+                                        int batch, int nx, int ny, double Lx, double rho, double nu, int precise, void* stream) {
+    return xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, precise, S(stream));
+}
+NNS_API int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                        float* r_u, float* r_v, float* r_div, int batch, int nx, int ny, double dt, double Ly,
+                                        double rho, double nu, int precise, void* stream) {
+    return ypass(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, Ly, rho, nu, precise, S(stream));
+}
+NNS_API int nns_spec_residual_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                  float* r_u, float* r_v, float* r_div, int batch, int nx, int ny, double dt, double Lx, double Ly,
+                                  double rho, double nu, int precise, void* stream) {
+    if (int rc = xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, precise, S(stream))) return rc;
+    return ypass(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, Ly, rho, nu, precise, S(stream));
+}

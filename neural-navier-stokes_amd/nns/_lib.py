@@ -1,0 +1,94 @@
+"""ctypes binding of libnns_hip.so (C ABI: include/nns.h).
+
+The HIP library is the product: there is NO CPU fallback.  If the shared object is missing the
+import of any op raises with build instructions -- it never degrades to NumPy/PyTorch math.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libnns_hip.so')
+NNS_MAX_BC = 8
+
+
+class BcList(C.Structure):
+    """struct nns_bc_list (include/nns.h)."""
+    _fields_ = [('n', C.c_int32), ('kind', C.c_int32 * NNS_MAX_BC), ('side', C.c_int32 * NNS_MAX_BC),
+                ('value', C.c_double * NNS_MAX_BC), ('dx', C.c_double * NNS_MAX_BC), ('dy', C.c_double * NNS_MAX_BC)]
+
+
+_lib = None
+
+_P, _I, _D, _SZ = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_BCP = C.POINTER(BcList)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); the fd/bc ops exist as _f32 and _f64
+_DUAL = {
+    'nns_bc_apply': [_P, _I, _I, _I, _BCP, _P],
+    'nns_fd_predictor_explicit': [_P] * 6 + [_I] * 3 + [_D] * 4 + [_P],
+    'nns_fd_predictor_adi': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
+    'nns_fd_pressure_rhs': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
+    'nns_fd_sor': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_fd_correction': [_P] * 5 + [_I] * 3 + [_D] * 3 + [_P],
+    'nns_fd_build_b': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
+    'nns_fd_jacobi': [_P] * 3 + [_I] * 3 + [_D] * 2 + [_I, _BCP, _P],
+    'nns_fd_direct_update': [_P] * 5 + [_I] * 3 + [_D] * 5 + [_P],
+    'nns_fd_residual': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
+}
+_SINGLE = {
+    'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
+    'nns_spec_residual_xpass_f32': [_P] * 6 + [_I] * 3 + [_D] * 3 + [_I, _P],
+    'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_fd_predictor_adi_workspace': [_I, _I, _I, _I],
+    'nns_fd_sor_workspace': [_I, _I, _I, _I],
+    'nns_device_info': [C.c_char_p, _I, C.POINTER(_I), C.POINTER(_SZ)],
+    'nns_version': [],
+    'nns_last_error': [],
+}
+_RESTYPES = {'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_last_error': C.c_char_p}
+
+
+def exported_names():
+    """Every symbol include/nns.h declares (used by the symbol-export test)."""
+    names = list(_SINGLE)
+    for base in _DUAL:
+        names += [base + '_f32', base + '_f64']
+    return sorted(names)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libnns_hip.so not found at %s.\nThe HIP extension is the product and has no CPU fallback: build it with\n"
+            "    make -C %s      (hipcc --offload-arch=gfx950)\nor  python -c 'import __graft_entry__ as g; g.build()'"
+            % (LIB_PATH, os.path.dirname(LIB_PATH)))
+    L = C.CDLL(LIB_PATH)
+    for base, args in _DUAL.items():
+        for suf in ('_f32', '_f64'):
+            f = getattr(L, base + suf)
+            f.argtypes, f.restype = args, C.c_int
+    for name, args in _SINGLE.items():
+        f = getattr(L, name)
+        f.argtypes, f.restype = args, _RESTYPES.get(name, C.c_int)
+    _lib = L
+    return L
+
+
+class NnsError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().nns_last_error()
+        raise NnsError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else '?'))
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus, mem = _I(0), _SZ(0)
+    check(lib().nns_device_info(name, 256, C.byref(cus), C.byref(mem)), 'nns_device_info')
+    return dict(name=name.value.decode(), cu_count=cus.value, hbm_bytes=mem.value)

@@ -1,0 +1,185 @@
+"""Thin, typed wrappers over the C ABI (include/nns.h) for torch device tensors.
+
+PyTorch is plumbing here (device memory + the current HIP stream); all arithmetic happens in the
+hand-written HIP kernels of csrc/.  Every function takes contiguous CUDA(HIP) tensors shaped
+[nx, ny] or [batch, nx, ny] in float32 or float64, enqueues ONE stream-ordered call on
+torch's current stream and returns its outputs as tensors.  Errors raise nns._lib.NnsError with
+the library's message; there is no CPU fallback.
+"""
+import torch
+
+from . import _lib
+from ._lib import BcList, check
+
+KIND = {'dirichlet': 0, 'neumann': 1}
+SIDE = {'left': 0, 'right': 1, 'bottom': 2, 'top': 3}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return '_f32'
+    if t.dtype == torch.float64:
+        return '_f64'
+    raise TypeError("fields must be float32 or float64, got %s" % t.dtype)
+
+
+def _dims(t):
+    if t.dim() == 2:
+        return 1, t.shape[0], t.shape[1]
+    if t.dim() == 3:
+        return t.shape[0], t.shape[1], t.shape[2]
+    raise ValueError("field must be [nx, ny] or [batch, nx, ny], got shape %s" % (tuple(t.shape),))
+
+
+def _chk(*ts):
+    t0 = ts[0]
+    for t in ts:
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise TypeError("expected a CUDA/HIP torch tensor (the HIP path has no CPU fallback)")
+        if not t.is_contiguous():
+            raise ValueError("fields must be C-contiguous")
+        if t.dtype != t0.dtype or t.shape != t0.shape or t.device != t0.device:
+            raise ValueError("all fields of one call must share dtype, shape and device")
+    return _suffix(t0), _dims(t0)
+
+
+def make_bc_list(bcs):
+    """bcs: iterable of objects with .type/.boundary/.value/.dx/.dy (nns.boundary classes or the
+    reference's own) or of (kind, side, value, dx, dy) tuples."""
+    out = BcList()
+    bcs = list(bcs)
+    if len(bcs) > _lib.NNS_MAX_BC:
+        raise ValueError("at most %d boundary conditions per list" % _lib.NNS_MAX_BC)
+    out.n = len(bcs)
+    for i, b in enumerate(bcs):
+        if isinstance(b, (tuple, list)):
+            kind, side, value, dx, dy = b
+        else:
+            kind, side, value, dx, dy = b.type, b.boundary, b.value, b.dx, b.dy
+        out.kind[i], out.side[i] = KIND[kind], SIDE[side]
+        out.value[i], out.dx[i], out.dy[i] = float(value), float(dx), float(dy)
+    return out
+
+
+def _call(name, suf, *args):
+    check(getattr(_lib.lib(), name + suf)(*args), name + suf)
+
+
+def _p(t):
+    return t.data_ptr()
+
+
+# ----------------------------------------------------------------------------- boundary
+def bc_apply_(A, bcs):
+    suf, (B, nx, ny) = _chk(A)
+    bl = bcs if isinstance(bcs, BcList) else make_bc_list(bcs)
+    _call('nns_bc_apply', suf, _p(A), B, nx, ny, bl, _stream())
+    return A
+
+
+# ----------------------------------------------------------------------------- chorin_fd
+def fd_predictor_explicit(un, vn, un1, vn1, dt, dx, dy, nu):
+    suf, (B, nx, ny) = _chk(un, vn, un1, vn1)
+    ui, vi = torch.empty_like(un), torch.empty_like(vn)
+    _call('nns_fd_predictor_explicit', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(ui), _p(vi), B, nx, ny,
+          dt, dx, dy, nu, _stream())
+    return ui, vi
+
+
+def fd_predictor_adi(un, vn, un1, vn1, dt, dx, dy, nu):
+    suf, (B, nx, ny) = _chk(un, vn, un1, vn1)
+    ui, vi = torch.empty_like(un), torch.empty_like(vn)
+    nbytes = _lib.lib().nns_fd_predictor_adi_workspace(B, nx, ny, un.element_size())
+    work = torch.empty(nbytes // un.element_size(), dtype=un.dtype, device=un.device)
+    _call('nns_fd_predictor_adi', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(ui), _p(vi), _p(work), B, nx, ny,
+          dt, dx, dy, nu, _stream())
+    return ui, vi
+
+
+def fd_pressure_rhs(ui, vi, dt, dx, dy, rho):
+    suf, (B, nx, ny) = _chk(ui, vi)
+    C = torch.empty_like(ui)
+    _call('nns_fd_pressure_rhs', suf, _p(ui), _p(vi), _p(C), B, nx, ny, dt, dx, dy, rho, _stream())
+    return C
+
+
+def fd_sor_(p, C, dx, dy, beta, tol, max_sweeps):
+    """In place on p.  Returns the device info tensor [batch, 2] = (sweeps done, last err)."""
+    suf, (B, nx, ny) = _chk(p, C)
+    info = torch.empty(B, 2, dtype=p.dtype, device=p.device)
+    nbytes = _lib.lib().nns_fd_sor_workspace(B, nx, ny, p.element_size())
+    work = torch.empty(nbytes // p.element_size(), dtype=p.dtype, device=p.device)
+    _call('nns_fd_sor', suf, _p(p), _p(C), _p(info), _p(work), B, nx, ny, dx, dy, beta, tol, int(max_sweeps), _stream())
+    return info
+
+
+def fd_correction(ui, vi, p, dt, dx, dy):
+    suf, (B, nx, ny) = _chk(ui, vi, p)
+    u, v = torch.empty_like(ui), torch.empty_like(vi)
+    _call('nns_fd_correction', suf, _p(ui), _p(vi), _p(p), _p(u), _p(v), B, nx, ny, dt, dx, dy, _stream())
+    return u, v
+
+
+# ----------------------------------------------------------------------------- direct_fd
+def fd_build_b(u, v, dt, dx, dy, rho):
+    suf, (B, nx, ny) = _chk(u, v)
+    b = torch.empty_like(u)
+    _call('nns_fd_build_b', suf, _p(u), _p(v), _p(b), B, nx, ny, dt, dx, dy, rho, _stream())
+    return b
+
+
+def fd_jacobi_(p, b, dx, dy, nit, p_bc):
+    suf, (B, nx, ny) = _chk(p, b)
+    bl = p_bc if isinstance(p_bc, BcList) else make_bc_list(p_bc)
+    tmp = torch.empty_like(p)
+    _call('nns_fd_jacobi', suf, _p(p), _p(tmp), _p(b), B, nx, ny, dx, dy, int(nit), bl, _stream())
+    return p
+
+
+def fd_direct_update(un, vn, p, dt, dx, dy, rho, nu):
+    suf, (B, nx, ny) = _chk(un, vn, p)
+    u, v = torch.empty_like(un), torch.empty_like(vn)
+    _call('nns_fd_direct_update', suf, _p(un), _p(vn), _p(p), _p(u), _p(v), B, nx, ny, dt, dx, dy, rho, nu, _stream())
+    return u, v
+
+
+# ----------------------------------------------------------------------------- periodic residual
+def fd_residual(u, v, p, u_prev, v_prev, dt, dx, dy, rho, nu, stencil=5, out=None):
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
+    ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
+    _call('nns_fd_residual', suf, _p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
+          dt, dx, dy, rho, nu, int(stencil), _stream())
+    return ru, rv, rd
+
+
+def spec_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, out=None):
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
+    if suf != '_f32':
+        raise TypeError("spec_residual: float32 fields (the forward transforms run in float64 internally)")
+    ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
+    check(_lib.lib().nns_spec_residual_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
+                                           dt, Lx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_f32')
+    return ru, rv, rd
+
+
+def spec_residual_xpass(u, v, p, Lx, rho, nu, precise=True, out=None):
+    suf, (B, nx, ny) = _chk(u, v, p)
+    if suf != '_f32':
+        raise TypeError("spec_residual_xpass: float32 fields")
+    ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
+    check(_lib.lib().nns_spec_residual_xpass_f32(_p(u), _p(v), _p(p), _p(ru), _p(rv), _p(rd), B, nx, ny, Lx, rho, nu,
+                                                 int(bool(precise)), _stream()), 'nns_spec_residual_xpass_f32')
+    return ru, rv, rd
+
+
+def spec_residual_ypass_(u, v, p, u_prev, v_prev, ru, rv, rd, dt, Ly, rho, nu, precise=True):
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev, ru, rv, rd)
+    if suf != '_f32':
+        raise TypeError("spec_residual_ypass: float32 fields")
+    check(_lib.lib().nns_spec_residual_ypass_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
+                                                 dt, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_ypass_f32')
+    return ru, rv, rd

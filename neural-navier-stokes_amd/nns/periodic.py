@@ -1,0 +1,41 @@
+"""Periodic-box incompressible Navier-Stokes residual engine (the north-star hot path).
+
+    r_u   = (u - u_prev)/dt + u u_x + v u_y + p_x/rho - nu lap u
+    r_v   = (v - v_prev)/dt + u v_x + v v_y + p_y/rho - nu lap v
+    r_div = u_x + v_y
+
+on batches of [B, nx, ny] float32 fields resident in HBM, with two derivative back-ends:
+  * 'fd5' / 'fd9'  -- 2nd-order central differences, 5- or 9-point Laplacian (csrc/residual_kernels.hip)
+  * 'spectral'     -- Fourier derivatives via LDS-resident FFTs (csrc/spectral_kernels.hip)
+The reference has no such operator (motivation
+src/neural_spectral/derivations/derivation.tex:25-59); oracle/periodic.py defines it and the
+tests pin both back-ends to it (1e-5 rel-L2 in float32).  Axis 0 = x, axis 1 = y.
+"""
+import math
+
+from . import ops
+
+
+class ResidualEngine(object):
+    def __init__(self, nx, ny, dt, rho, nu, Lx=2 * math.pi, Ly=2 * math.pi, backend='spectral', precise=True):
+        if backend not in ('fd5', 'fd9', 'spectral'):
+            raise ValueError("backend must be 'fd5', 'fd9' or 'spectral'")
+        self.nx, self.ny, self.dt, self.rho, self.nu = nx, ny, dt, rho, nu
+        self.Lx, self.Ly = Lx, Ly
+        self.dx, self.dy = Lx / nx, Ly / ny
+        self.backend, self.precise = backend, precise
+
+    def fd(self, u, v, p, u_prev, v_prev, stencil=5, out=None):
+        return ops.fd_residual(u, v, p, u_prev, v_prev, self.dt, self.dx, self.dy, self.rho, self.nu, stencil, out)
+
+    def spectral(self, u, v, p, u_prev, v_prev, out=None):
+        return ops.spec_residual(u, v, p, u_prev, v_prev, self.dt, self.Lx, self.Ly, self.rho, self.nu, self.precise, out)
+
+    def __call__(self, u, v, p, u_prev, v_prev, out=None):
+        if self.backend == 'spectral':
+            return self.spectral(u, v, p, u_prev, v_prev, out)
+        return self.fd(u, v, p, u_prev, v_prev, 5 if self.backend == 'fd5' else 9, out)
+
+    def both(self, u, v, p, u_prev, v_prev, out_fd=None, out_spec=None, stencil=5):
+        """The 'stencil + spectral residual' of BASELINE.json: both back-ends on the same inputs."""
+        return (self.fd(u, v, p, u_prev, v_prev, stencil, out_fd), self.spectral(u, v, p, u_prev, v_prev, out_spec))

@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/nns.h declares (no compute calls without a GPU); the product never imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, PKG
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'nns.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(nns_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_declares_what_the_binding_binds():
+    from nns import _lib
+    assert declared_symbols() == _lib.exported_names()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from nns import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert _lib.lib().nns_version() == 1          # major 0, minor 1
+    assert _lib.lib().nns_last_error() is not None
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from nns import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libnns_hip.so')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(PKG):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.cpp', '.h')):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M) or 'oracle/_ref' in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_reference_import_paths_resolve_to_nns():
+    import src.boundary as B
+    import nns.boundary
+    assert B.DirichletBoundaryCondition is nns.boundary.DirichletBoundaryCondition
+    bc = B.NeumannBoundaryCondition(0.5, 'left', 0.1, 0.2)
+    assert (bc.type, bc.boundary, bc.value, bc.dx, bc.dy) == ('neumann', 'left', 0.5, 0.1, 0.2)
+    with pytest.raises(AssertionError):
+        B.DirichletBoundaryCondition(0, 'left', 1, 0.2)          # dx must be float (src/boundary.py:17)
+    with pytest.raises(AssertionError):
+        B.DirichletBoundaryCondition(0, 'front', 0.1, 0.2)

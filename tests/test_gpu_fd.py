@@ -1,0 +1,304 @@
+"""GPU parity (through the C ABI): boundary conditions, chorin_fd and direct_fd operators vs the
+golden vectors captured from the reference and vs the CPU oracle.
+
+Tolerances: float64 kernels keep the reference's operation order (no FMA contraction): stencils
+must agree to 1e-13 rel-L2 (typically bitwise), SOR to 1e-12 with the exact sweep count; the
+ADI solves go through LAPACK in the reference: 1e-10.  float32 kernels: 1e-5 rel-L2 (north-star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, unpack_bcs, rel_l2, KINDS, SIDES
+
+pytestmark = pytest.mark.gpu
+
+F64, F32 = 1e-13, 1e-5
+
+
+def dev(a, dtype=np.float64):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=dtype), device='cuda')
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def objs(bcs):
+    from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+    return [(D if k == 'dirichlet' else N)(v, s, dx, dy) for (k, s, v, dx, dy) in bcs]
+
+
+# ------------------------------------------------------------------ a1 boundary
+def test_bc_single_numpy_and_tensor(gpu_device):
+    from nns import boundary as B
+    g = load_golden('boundary.npz')
+    val, dx, dy = float(g['single_value']), float(g['single_dx']), float(g['single_dy'])
+    for kind, cls in (('dirichlet', B.DirichletBoundaryCondition), ('neumann', B.NeumannBoundaryCondition)):
+        for side in SIDES:
+            A = g['A0'].copy()
+            r = cls(val, side, dx, dy).apply(A)
+            assert r is A                                           # mutates and returns the same object
+            np.testing.assert_array_equal(A, g['%s_%s' % (kind, side)])
+            T = dev(g['A0'], np.float32)
+            r = cls(val, side, dx, dy).apply(T)
+            assert r is T
+            assert rel_l2(host(T), g['%s_%s' % (kind, side)]) < 1e-6
+
+
+@pytest.mark.parametrize('name', ['u', 'v', 'p', 'mixed'])
+def test_bc_list_corner_order_batched(name, gpu_device):
+    from nns import ops
+    g = load_golden('boundary.npz')
+    bcs = unpack_bcs(g, 'list_%s_bc' % name)
+    A = dev(np.stack([g['S0'], 2 * g['S0'], -g['S0']]))
+    ops.bc_apply_(A, bcs)
+    np.testing.assert_array_equal(host(A[0]), g['list_' + name])
+    from oracle.boundary import apply_bc_list
+    np.testing.assert_array_equal(host(A[1]), apply_bc_list(2 * g['S0'].copy(), bcs))
+    np.testing.assert_array_equal(host(A[2]), apply_bc_list(-g['S0'].copy(), bcs))
+
+
+def test_bc_non_square_and_errors(gpu_device):
+    from nns import ops, _lib
+    from oracle.boundary import apply_bc_list
+    rng = np.random.default_rng(3)
+    A0 = rng.standard_normal((2, 37, 300))
+    bcs = [('neumann', 'top', 0.3, 0.1, 0.2), ('dirichlet', 'left', 1.0, 0.1, 0.2), ('neumann', 'right', -2.0, 0.1, 0.2),
+           ('neumann', 'bottom', 0.7, 0.1, 0.2)]
+    A = dev(A0)
+    ops.bc_apply_(A, bcs)
+    np.testing.assert_array_equal(host(A), apply_bc_list(A0.copy(), bcs))
+    with pytest.raises(ValueError):
+        ops.bc_apply_(A, bcs * 3)                                   # > NNS_MAX_BC entries
+    with pytest.raises(TypeError):
+        ops.bc_apply_(torch.zeros(4, 4, dtype=torch.float64), bcs)  # CPU tensor: no fallback
+    with pytest.raises(_lib.NnsError):
+        ops.bc_apply_(dev(np.zeros((2, 2))), bcs)                   # nx, ny >= 3
+
+
+# ------------------------------------------------------------------ a2, a3, a5 chorin_fd stencils
+@pytest.mark.parametrize('n', [16, 64])
+def test_chorin_fd_predictors_and_correction(n, gpu_device):
+    from nns import ops
+    g = load_golden('chorin_fd_ops_%d.npz' % n)
+    dt, rho, nu, beta, dx, dy = [float(x) for x in g['params']]
+    for dtype, tol_s, tol_adi in ((np.float64, F64, 1e-10), (np.float32, F32, F32)):
+        u, v, u1, v1, p0 = (dev(g[k], dtype) for k in ('u', 'v', 'u1', 'v1', 'p0'))
+        ui, vi = ops.fd_predictor_explicit(u, v, u1, v1, dt, dx, dy, nu)
+        assert rel_l2(host(ui), g['pred_explicit_ui']) <= tol_s and rel_l2(host(vi), g['pred_explicit_vi']) <= tol_s
+        ui, vi = ops.fd_predictor_adi(u, v, u1, v1, dt, dx, dy, nu)
+        assert rel_l2(host(ui), g['pred_semi_implicit_ui']) <= tol_adi and rel_l2(host(vi), g['pred_semi_implicit_vi']) <= tol_adi
+        a, b = ops.fd_correction(u, v, p0, dt, dx, dy)
+        assert rel_l2(host(a), g['corr_u']) <= tol_s and rel_l2(host(b), g['corr_v']) <= tol_s
+
+
+def test_chorin_fd_f64_explicit_is_bitwise(gpu_device):
+    from nns import ops
+    g = load_golden('chorin_fd_ops_64.npz')
+    dt, rho, nu, beta, dx, dy = [float(x) for x in g['params']]
+    ui, vi = ops.fd_predictor_explicit(dev(g['u']), dev(g['v']), dev(g['u1']), dev(g['v1']), dt, dx, dy, nu)
+    np.testing.assert_array_equal(host(ui), g['pred_explicit_ui'])
+    np.testing.assert_array_equal(host(vi), g['pred_explicit_vi'])
+
+
+def test_adi_rejects_non_square(gpu_device):
+    from nns import ops, _lib
+    z = dev(np.zeros((8, 12)))
+    with pytest.raises(_lib.NnsError, match='nx == ny'):
+        ops.fd_predictor_adi(z, z, z, z, 1e-3, 0.1, 0.1, 0.1)
+
+
+@pytest.mark.parametrize('shape', [(3, 33, 70), (2, 130, 45)])
+def test_stencils_vs_oracle_ragged_batched(shape, gpu_device):
+    """Non-square, non-multiple-of-anything sizes, batch > 1, against the oracle."""
+    from nns import ops
+    from oracle import chorin_fd as OC, direct_fd as OD
+    rng = np.random.default_rng(11)
+    u, v, u1, v1, p = (rng.standard_normal(shape) for _ in range(5))
+    dt, dx, dy, nu, rho = 1e-3, 2. / (shape[1] - 1), 2. / (shape[2] - 1), 0.05, 1.3
+    ui, vi = ops.fd_predictor_explicit(dev(u), dev(v), dev(u1), dev(v1), dt, dx, dy, nu)
+    a, b = OC.explicit_predictor(u, v, u1, v1, dt, dx, dy, nu)
+    assert rel_l2(host(ui), a) <= F64 and rel_l2(host(vi), b) <= F64
+    C = ops.fd_pressure_rhs(dev(u), dev(v), dt, dx, dy, rho)
+    assert rel_l2(host(C), OC.pressure_rhs(u, v, dt, dx, dy, rho)) <= F64
+    a, b = ops.fd_correction(dev(u), dev(v), dev(p), dt, dx, dy)
+    ra, rb = OC.correction(u, v, p, dt, dx, dy)
+    assert rel_l2(host(a), ra) <= F64 and rel_l2(host(b), rb) <= F64
+    bb = ops.fd_build_b(dev(u), dev(v), dt, dx, dy, rho)
+    assert rel_l2(host(bb), OD.build_up_b(u, v, dt, dx, dy, rho)) <= F64
+    a, b = ops.fd_direct_update(dev(u), dev(v), dev(p), dt, dx, dy, rho, nu)
+    ra, rb = OD.momentum_update(u, v, p, dt, dx, dy, rho, nu)
+    assert rel_l2(host(a), ra) <= F64 and rel_l2(host(b), rb) <= F64
+
+
+# ------------------------------------------------------------------ a4 SOR
+@pytest.mark.parametrize('n', [16, 64])
+@pytest.mark.parametrize('nit', [3, 50, 400])
+def test_sor_matches_reference_and_sweep_count(n, nit, gpu_device):
+    from nns import ops
+    from nns.chorin_fd import SOR_TOL
+    g = load_golden('chorin_fd_ops_%d.npz' % n)
+    dt, rho, nu, beta, dx, dy = [float(x) for x in g['params']]
+    C = ops.fd_pressure_rhs(dev(g['press_ui']), dev(g['press_vi']), dt, dx, dy, rho)
+    p = dev(g['press_p0_nit%d' % nit])
+    info = host(ops.fd_sor_(p, C, dx, dy, beta, SOR_TOL, nit - 1))
+    assert int(info[0, 0]) == int(g['press_sweeps_nit%d' % nit])
+    assert rel_l2(host(p), g['press_p_nit%d' % nit]) <= 1e-12
+    assert abs(info[0, 1] - float(g['press_err_nit%d' % nit])) <= 1e-12 * max(1.0, abs(float(g['press_err_nit%d' % nit])))
+    # float32: fields within 1e-5, sweep count may differ by one at the tolerance boundary
+    C32 = ops.fd_pressure_rhs(dev(g['press_ui'], np.float32), dev(g['press_vi'], np.float32), dt, dx, dy, rho)
+    p32 = dev(g['press_p0_nit%d' % nit], np.float32)
+    info32 = host(ops.fd_sor_(p32, C32, dx, dy, beta, SOR_TOL, nit - 1))
+    assert abs(int(info32[0, 0]) - int(g['press_sweeps_nit%d' % nit])) <= (1 if nit == 400 else 0)
+    assert rel_l2(host(p32), g['press_p_nit%d' % nit]) <= 2e-5
+
+
+def test_sor_batched_replicas_large_global_memory_path_and_determinism(gpu_device):
+    """Batch of different grids (one stops early, one does not), a grid too large for the LDS-resident
+    path (global-memory variant), and run-to-run bitwise determinism (catches LDS/pipeline races)."""
+    from nns import ops
+    from oracle import chorin_fd as OC
+    rng = np.random.default_rng(2)
+    n = 150                                                 # 2 * 150^2 * 8 B > 150 KB -> global path in f64
+    dx = dy = 2. / (n - 1)
+    P0 = np.stack([1e-4 * rng.standard_normal((n, n)), 0.5 * rng.standard_normal((n, n))])
+    Cc = np.stack([1e-7 * rng.standard_normal((n, n)), 1e-2 * rng.standard_normal((n, n))])
+    for c in Cc:
+        c[0, :] = c[-1, :] = 0; c[:, 0] = c[:, -1] = 0
+    outs = []
+    for rep in range(2):
+        p = dev(P0)
+        info = host(ops.fd_sor_(p, dev(Cc), dx, dy, 1.25, 5e-6, 40))
+        outs.append((host(p), info))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    for b in range(2):
+        pr = P0[b].copy()
+        err, sweeps = 1.0, 0
+        prev = pr.copy()
+        while err > 5e-6 and sweeps < 40:
+            OC.sor_sweep_wavefront(pr, Cc[b], dx, dy, 1.25)
+            err = np.abs(pr - prev).max(); prev = pr.copy(); sweeps += 1
+        assert int(outs[0][1][b, 0]) == sweeps
+        assert rel_l2(outs[0][0][b], pr) <= 1e-12
+    assert int(outs[0][1][0, 0]) < 40 and int(outs[0][1][1, 0]) == 40
+
+
+# ------------------------------------------------------------------ a6 step / simulate through the reference call surface
+@pytest.mark.parametrize('n', [16, 64])
+@pytest.mark.parametrize('method', ['explicit', 'semi_implicit'])
+def test_chorin_fd_step_surface(n, method, gpu_device):
+    from src.chorin_fd.simulate import NavierStokesSystem
+    g = load_golden('chorin_fd_ops_%d.npz' % n)
+    dt, rho, nu, beta, dx, dy = [float(x) for x in g['params']]
+    u_bc, v_bc, p_bc = (objs(unpack_bcs(g, k + '_bc')) for k in 'uvp')
+    s = NavierStokesSystem(None, None, None, u_bc, v_bc, p_bc, nt=1, nit=20, nx=n, ny=n, dt=dt, rho=rho, nu=nu,
+                           beta=beta, method=method)
+    p = 0.01 * g['p0'].copy()
+    a, b, c = s.step(0.1 * g['u'], 0.1 * g['v'], 0.1 * g['u1'], 0.1 * g['v1'], p)
+    assert c is p                                              # p mutated in place and returned
+    tol = 1e-12 if method == 'explicit' else 1e-9
+    for got, key in ((a, 'u'), (b, 'v'), (c, 'p')):
+        assert rel_l2(got, g['step_%s_%s' % (method, key)]) <= tol
+    assert s.sor_info()[0][0] == int(g['step_%s_sweeps' % method])
+    with pytest.raises(AssertionError):
+        NavierStokesSystem(None, None, None, u_bc, v_bc, p_bc, method='implicit')
+
+
+@pytest.mark.parametrize('case', [(16, 'explicit', 0.1), (16, 'semi_implicit', 0.1), (64, 'explicit', 0.02),
+                                  (64, 'explicit', 0.01), (64, 'semi_implicit', 0.02), (64, 'semi_implicit', 0.01)])
+def test_chorin_fd_cavity_trajectory(case, gpu_device):
+    """BASELINE config 1 (64x64 lid-driven cavity, Re = 100) and the 16x16 case, f64 and f32."""
+    from src.chorin_fd.simulate import NavierStokesSystem
+    from src.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+    n, method, nu = case
+    g = load_golden('chorin_fd_cavity_%d_%s_nu%g.npz' % (n, method, nu))
+    dt, rho, nu_, beta, dx, dy = [float(x) for x in g['params']]
+    u_bc = [D(0, 'left', dx, dy), D(1, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
+    v_bc = [D(0, 'left', dx, dy), D(0, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
+    p_bc = [D(0, 'top', dx, dy), N(0, 'bottom', dx, dy), N(0, 'left', dx, dy), N(0, 'right', dx, dy)]
+    sel = slice(None) if n == 16 else [0, -1]
+    for dtype, tol in ((np.float64, 1e-9), (np.float32, 2e-5)):
+        z = np.zeros((n, n))
+        s = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=int(g['nt']), nit=int(g['nit']), nx=n, ny=n,
+                               dt=dt, rho=rho, nu=nu_, beta=beta, method=method, dtype=dtype)
+        ul, vl, pl = s.simulate()
+        assert ul.dtype == np.float64 and ul.shape == (int(g['nt']), n, n)
+        assert rel_l2(ul[sel], g['u']) <= tol and rel_l2(vl[sel], g['v']) <= tol and rel_l2(pl[sel], g['p']) <= tol
+
+
+def test_chorin_fd_ensemble_batch_equals_singles(gpu_device):
+    from nns.chorin_fd import NavierStokesSystem
+    from oracle.boundary import cavity_bcs
+    n = 32
+    dx = dy = 2. / (n - 1)
+    u_bc, v_bc, p_bc = cavity_bcs(dx, dy)
+    rng = np.random.default_rng(9)
+    U = 0.05 * rng.standard_normal((3, n, n))
+    kw = dict(nt=3, nit=30, nx=n, ny=n, dt=1e-3, rho=1, nu=0.05, beta=1.25, method='explicit')
+    ub, vb, pb = NavierStokesSystem(U, 0 * U, 0 * U, u_bc, v_bc, p_bc, **kw).simulate()
+    assert ub.shape == (3, 3, n, n)
+    for b in range(3):
+        u1, v1, p1 = NavierStokesSystem(U[b], 0 * U[b], 0 * U[b], u_bc, v_bc, p_bc, **kw).simulate()
+        np.testing.assert_array_equal(ub[:, b], u1)
+        np.testing.assert_array_equal(pb[:, b], p1)
+
+
+# ------------------------------------------------------------------ a7-a9 direct_fd
+@pytest.mark.parametrize('n', [16, 64])
+def test_direct_fd_operators_and_step(n, gpu_device):
+    from src.direct_fd.simulate import NavierStokesSystem
+    g = load_golden('direct_fd_ops_%d.npz' % n)
+    dt, rho, nu, dx, dy = [float(x) for x in g['params']]
+    u_bc, v_bc, p_bc = (objs(unpack_bcs(g, k + '_bc')) for k in 'uvp')
+    s = NavierStokesSystem(None, None, None, u_bc, v_bc, p_bc, nt=1, nit=50, nx=n, ny=n, dt=dt, rho=rho, nu=nu)
+    b = s._build_up_b(g['u'], g['v'])
+    assert rel_l2(b, g['b']) <= F64
+    for nit in (1, 50):
+        s.nit = nit
+        p = g['p0'].copy()
+        r = s._pressure_poisson(p, 1e-3 * g['b'])
+        assert r is p
+        assert rel_l2(p, g['poisson_nit%d' % nit]) <= F64
+    s.nit = 20
+    u, v, p = 0.1 * g['u'], 0.1 * g['v'], 0.01 * g['p0']
+    ru, rv, rp = s.step(u, v, p)
+    assert ru is u and rv is v and rp is p                           # in place, as the reference
+    assert rel_l2(u, g['step_u']) <= F64 and rel_l2(v, g['step_v']) <= F64 and rel_l2(p, g['step_p']) <= F64
+
+
+def test_direct_fd_jacobi_large_grid_multilaunch_path(gpu_device):
+    """A grid too large for the LDS-resident Jacobi: ping-pong launches + BC kernel, odd and even nit."""
+    from nns import ops
+    from oracle import direct_fd as OD
+    rng = np.random.default_rng(4)
+    n, m = 140, 170
+    dx, dy = 2. / (n - 1), 2. / (m - 1)
+    p0, b = rng.standard_normal((2, n, m)), rng.standard_normal((2, n, m))
+    bcs = [('dirichlet', 'top', 0.0, dx, dy), ('neumann', 'bottom', 0.2, dx, dy), ('neumann', 'left', 0.0, dx, dy),
+           ('neumann', 'right', -0.1, dx, dy)]
+    for nit in (3, 4):
+        p = dev(p0)
+        ops.fd_jacobi_(p, dev(b), dx, dy, nit, bcs)
+        ref = p0.copy()
+        for k in range(2):
+            OD.pressure_poisson(ref[k], b[k], bcs, dx, dy, nit)
+        assert rel_l2(host(p), ref) <= F64
+
+
+@pytest.mark.parametrize('n', [16, 64])
+def test_direct_fd_cavity_trajectory(n, gpu_device):
+    from src.direct_fd.simulate import NavierStokesSystem
+    from oracle.boundary import cavity_bcs
+    g = load_golden('direct_fd_cavity_%d.npz' % n)
+    dt, rho, nu, dx, dy = [float(x) for x in g['params']]
+    u_bc, v_bc, p_bc = (objs(b) for b in cavity_bcs(dx, dy))
+    sel = slice(None) if n == 16 else [0, -1]
+    for dtype, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        z = np.zeros((n, n))
+        u_ic = z.copy()
+        s = NavierStokesSystem(u_ic, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=int(g['nt']), nit=int(g['nit']), nx=n, ny=n,
+                               dt=dt, rho=rho, nu=nu, dtype=dtype)
+        ul, vl, pl = s.simulate()
+        assert rel_l2(ul[sel], g['u']) <= tol and rel_l2(vl[sel], g['v']) <= tol and rel_l2(pl[sel], g['p']) <= tol
+        assert np.abs(u_ic).max() > 0                        # the reference's simulate mutates the caller's ICs (:132)

@@ -1,0 +1,163 @@
+"""GPU parity of the periodic-box Navier-Stokes residual (FD 5/9-point and Fourier-spectral
+back-ends) against the CPU oracle (oracle/periodic.py), through the C ABI.
+
+Tolerance (BASELINE.json north_star): fields within 1e-5 rel-L2 of the float64 CPU reference, for
+float32 device fields.  The float64 FD kernel is held to 1e-12.  Full-size cases (1024^2, batch
+64) are checked through size-independent properties: the analytic Taylor-Green answer, batch
+independence (grid b of a batch == the same grid alone, bitwise) and x/y symmetry.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+NU, RHO, DT = 2 * np.pi / 1000, 1.0, 1e-3
+L = 2 * np.pi
+TOL = 1e-5
+
+
+def dev(a, dtype=np.float32):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=dtype), device='cuda')
+
+
+def host(ts):
+    return [t.cpu().numpy() for t in ts]
+
+
+def inputs(batch, n, dtype=np.float32, **kw):
+    from nns.synthetic import residual_inputs
+    return residual_inputs(batch, n, dt=DT, nu=NU, rho=RHO, dtype=dtype, **kw)
+
+
+@pytest.mark.parametrize('n', [64, 128, 256, 512, 1024])
+@pytest.mark.parametrize('stencil', [5, 9])
+def test_fd_residual_vs_oracle(n, stencil, gpu_device):
+    from nns import ops
+    from oracle import periodic as OP
+    f = inputs(2, n)
+    h = L / n
+    got = host(ops.fd_residual(*[dev(a) for a in f], DT, h, h, RHO, NU, stencil))
+    ref = OP.fd_residual(*[a.astype(np.float64) for a in f], DT, h, h, RHO, NU, stencil)
+    for g, r in zip(got, ref):
+        assert rel_l2(g, r) <= TOL
+    got64 = host(ops.fd_residual(*[dev(a, np.float64) for a in f], DT, h, h, RHO, NU, stencil))
+    for g, r in zip(got64, ref):
+        assert rel_l2(g, r) <= 1e-12
+
+
+@pytest.mark.parametrize('shape', [(1, 48, 200), (3, 100, 36), (2, 33, 50), (1, 7, 8)])
+def test_fd_residual_ragged_sizes_both_paths(shape, gpu_device):
+    """ny not a multiple of 256 / of the vector width (generic fallback kernel), nx != ny, dx != dy."""
+    from nns import ops
+    from oracle import periodic as OP
+    rng = np.random.default_rng(7)
+    f = [rng.standard_normal(shape) for _ in range(5)]
+    dx, dy = 0.07, 0.11
+    for stencil in (5, 9):
+        ref = OP.fd_residual(*f, 0.01, dx, dy, 1.7, 0.03, stencil)
+        got = host(ops.fd_residual(*[dev(a, np.float64) for a in f], 0.01, dx, dy, 1.7, 0.03, stencil))
+        for g, r in zip(got, ref):
+            assert rel_l2(g, r) <= 1e-12
+        got = host(ops.fd_residual(*[dev(a) for a in f], 0.01, dx, dy, 1.7, 0.03, stencil))
+        for g, r in zip(got, ref):
+            assert rel_l2(g, r) <= TOL
+
+
+@pytest.mark.parametrize('n', [64, 128, 256, 512, 1024])
+def test_spectral_residual_vs_oracle(n, gpu_device):
+    from nns import ops
+    from oracle import periodic as OP
+    f = inputs(2, n)
+    got = host(ops.spec_residual(*[dev(a) for a in f], DT, L, L, RHO, NU, precise=True))
+    ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], DT, L, L, RHO, NU)
+    for g, r in zip(got, ref):
+        assert rel_l2(g, r) <= TOL
+    # the all-float32 fast mode is documented at ~2e-4 (forward rounding noise amplified by k)
+    fast = host(ops.spec_residual(*[dev(a) for a in f], DT, L, L, RHO, NU, precise=False))
+    for g, r in zip(fast, ref):
+        assert rel_l2(g, r) <= 2e-3
+
+
+def test_spectral_residual_non_square_and_box_lengths(gpu_device):
+    from nns import ops
+    from oracle import periodic as OP
+    rng = np.random.default_rng(8)
+    nx, ny = 128, 256
+    x = np.arange(nx)[:, None] / nx
+    y = np.arange(ny)[None, :] / ny
+    mk = lambda: (np.sin(2 * np.pi * (2 * x + rng.uniform())) * np.cos(2 * np.pi * (3 * y + rng.uniform())) +
+                  0.01 * rng.standard_normal((nx, ny))).astype(np.float32)[None]
+    f = [mk() for _ in range(5)]
+    Lx, Ly = 1.5, 4.0
+    got = host(ops.spec_residual(*[dev(a) for a in f], 2e-3, Lx, Ly, 1.2, 0.01))
+    ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], 2e-3, Lx, Ly, 1.2, 0.01)
+    for g, r in zip(got, ref):
+        assert rel_l2(g, r) <= TOL
+
+
+def test_spectral_nyquist_and_single_modes(gpu_device):
+    """Edge cases of the operator definition: the Nyquist mode is dropped by odd derivatives and kept by
+    the Laplacian; single Fourier modes are differentiated exactly."""
+    from nns import ops
+    n = 64
+    x = L * np.arange(n) / n
+    X, Y = np.meshgrid(x, x, indexing='ij')
+    z = np.zeros((1, n, n), np.float32)
+    u = (np.cos((n // 2) * X))[None].astype(np.float32)                 # x-Nyquist mode only
+    ru, rv, rd = host(ops.spec_residual(dev(u), dev(z), dev(z), dev(u), dev(z), 1.0, L, L, 1.0, 1.0))
+    assert np.abs(rd).max() < 1e-4                                      # u_x of the Nyquist mode -> 0
+    assert rel_l2(ru, (n // 2) ** 2 * u) < 1e-5                         # -nu lap u = +k^2 u   (u u_x = 0)
+    u = (np.sin(3 * X) * np.cos(2 * Y))[None].astype(np.float32)
+    ru, rv, rd = host(ops.spec_residual(dev(u), dev(z), dev(z), dev(u), dev(z), 1.0, L, L, 1.0, 0.0))
+    assert rel_l2(rd, 3 * np.cos(3 * X) * np.cos(2 * Y)) < 1e-5
+
+
+def test_spectral_unsupported_sizes_raise(gpu_device):
+    from nns import ops, _lib
+    z = torch.zeros(1, 96, 64, device='cuda')
+    with pytest.raises(_lib.NnsError, match='power of two'):
+        ops.spec_residual(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
+    z = torch.zeros(1, 64, 2048, device='cuda')
+    with pytest.raises(_lib.NnsError):
+        ops.spec_residual(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
+
+
+def test_split_passes_equal_fused_call(gpu_device):
+    from nns import ops
+    f = [dev(a) for a in inputs(2, 256)]
+    full = host(ops.spec_residual(*f, DT, L, L, RHO, NU))
+    out = ops.spec_residual_xpass(f[0], f[1], f[2], L, RHO, NU)
+    ops.spec_residual_ypass_(*f, *out, DT, L, RHO, NU)
+    for a, b in zip(full, host(out)):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_full_size_properties_1024_batch64(gpu_device):
+    """BASELINE workload size (1024^2, batch 64): analytic Taylor-Green answer, batch independence,
+    determinism, and FD-vs-spectral consistency at the truncation-error level."""
+    from nns.periodic import ResidualEngine
+    from nns.synthetic import taylor_green
+    n, B = 1024, 64
+    u0, v0, p0 = taylor_green(n, 0.1, NU, RHO)
+    up0, vp0, _ = taylor_green(n, 0.1 - DT, NU, RHO)
+    f1 = [dev(a[None]) for a in (u0, v0, p0, up0, vp0)]
+    eng = ResidualEngine(n, n, DT, RHO, NU, backend='spectral')
+    ru, rv, rd = host(eng(*f1))
+    # exact NS solution: residual = time-discretisation error 2 nu^2 dt |u| + float32 rounding of (u-u_prev)/dt
+    assert np.abs(ru).max() < 2e-4 and np.abs(rv).max() < 2e-4 and np.abs(rd).max() < 2e-5
+    fd = host(eng.fd(*f1, stencil=5))
+    assert np.abs(fd[0]).max() < 5e-4                                    # O(h^2) = (2 pi/1024)^2 ~ 4e-5 scale
+    # batch independence + determinism on the noisy batch
+    fb = [dev(a) for a in inputs(4, n)]
+    big = [t.repeat(16, 1, 1).contiguous() for t in fb]                   # B = 64
+    assert big[0].shape[0] == B
+    for call in (eng.spectral, lambda *a: eng.fd(*a, stencil=9)):
+        r64 = call(*big)
+        r64b = call(*big)
+        r4 = call(*fb)
+        for a, b, c in zip(r64, r64b, r4):
+            assert torch.equal(a, b)                                      # run-to-run bitwise
+            assert torch.equal(a[:4], c) and torch.equal(a[60:], c)       # grid b of the batch == grid alone
