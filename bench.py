@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grid-point residual-updates/sec at 1024^2 (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+the incompressible Navier-Stokes residual (r_u, r_v, r_div) of B = 64 independent 1024x1024
+periodic boxes evaluated with BOTH derivative back-ends on the same inputs -- the 5-point finite-
+difference stencil (csrc/residual_kernels.hip) and the Fourier-spectral path (two LDS-resident FFT
+passes, csrc/spectral_kernels.hip).  One residual update = one grid point through both.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: the batch axis is the unit that shards (independent grids): every rank owns its own 64
+grids, no data-path collective, "scaling": "weak"; timing = barrier + synchronize on both sides,
+max over ranks.  (The slab-decomposed single-grid mode with RCCL halo / all-to-all is exercised
+by `--mode slab`, see nns/slab.py.)
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- for the dominant kernel: algorithmic bytes per launch / its average launch time,
+                  measured here with HIP events on the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the NumPy oracle (oracle/periodic.py, kind "port") timed on this host on a bounded
+                  sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'neural-navier-stokes_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+# algorithmic (compulsory) HBM bytes per grid point, float32 fields -- derivation in DESIGN.md
+BYTES_PER_PT = {'fd_residual': 32.0, 'spec_xpass': 24.0, 'spec_ypass': 44.0}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_inputs(batch, n, distinct, seed0, device):
+    from nns.synthetic import residual_inputs
+    d = max(1, min(distinct, batch))
+    f = residual_inputs(d, n, seed0=seed0)
+    reps = (batch + d - 1) // d
+    return [torch.as_tensor(np.tile(a, (reps, 1, 1))[:batch], device=device).contiguous() for a in f]
+
+
+def time_kernel(fn, iters):
+    """Average launch duration (ms) of fn() over `iters` back-to-back launches, HIP events on the
+    current stream (the stream the kernels are enqueued on)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(n, budget_s=20.0):
+    """The NumPy oracle (float64) on this host: FD 5-point + spectral residual of single 1024^2 grids,
+    repeated until ~budget_s of CPU time."""
+    from oracle import periodic as OP
+    from nns.synthetic import residual_inputs
+    f = [a[0].astype(np.float64) for a in residual_inputs(1, n)]
+    dt, nu, rho, L = 1e-3, 2 * np.pi / 1000, 1.0, 2 * np.pi
+    h = L / n
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        OP.fd_residual(*f, dt, h, h, rho, nu, 5)
+        OP.spectral_residual(*f, dt, L, L, rho, nu)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 400:
+            break
+    return dict(value=reps * n * n / el, unit='residual-updates/s', cores=1, kind='port',
+                sample='%d x (FD 5-point + rfft2 spectral residual) of one %dx%d float64 grid, NumPy oracle, %.1f s'
+                       % (reps, n, n, el), host_cores_present=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--n', type=int, default=1024)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--distinct', type=int, default=8, help='distinct synthetic grids generated on the host (tiled to --batch)')
+    ap.add_argument('--stencil', type=int, default=5)
+    ap.add_argument('--fast', action='store_true', help='all-float32 spectral path (2e-4 rel-L2) instead of the precise one')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)          # "nccl" is RCCL on ROCm
+
+    from nns import ops, _lib
+    from nns.periodic import ResidualEngine
+    n, B = args.n, args.batch
+    dt, nu, rho, L = 1e-3, 2 * np.pi / 1000, 1.0, 2 * np.pi
+    if rank == 0:
+        log('bench: device', _lib.device_info(), 'world', world)
+        log('bench: generating %d distinct %dx%d grids on the host ...' % (min(args.distinct, B), n, n))
+    f = make_inputs(B, n, args.distinct, 1234 + 1000 * rank, device)
+    eng = ResidualEngine(n, n, dt, rho, nu, L, L, backend='spectral', precise=not args.fast)
+    out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
+    out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
+
+    def step():
+        eng.fd(*f, stencil=args.stencil, out=out_fd)
+        eng.spectral(*f, out=out_sp)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pts = float(B) * n * n
+    value = world * pts * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # per-kernel durations, live, for the roofline object (same process, same inputs)
+        iters = max(5, args.steps)
+        kt = {
+            'fd_residual': time_kernel(lambda: eng.fd(*f, stencil=args.stencil, out=out_fd), iters),
+            'spec_xpass': time_kernel(lambda: ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, not args.fast, out=out_sp), iters),
+            'spec_ypass': time_kernel(lambda: ops.spec_residual_ypass_(*f, *out_sp, dt, L, rho, nu, not args.fast), iters),
+        }
+        dom = max(kt, key=kt.get)
+        alg_bytes = BYTES_PER_PT[dom] * pts
+        achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                        traffic=traffic, algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=kt[dom],
+                        all_kernels={k: dict(avg_launch_ms=v, bytes_per_pt=BYTES_PER_PT[k],
+                                             achieved_GBs=BYTES_PER_PT[k] * pts / (v * 1e-3) / 1e9) for k, v in kt.items()})
+        result = dict(metric='grid-point residual-updates/sec at 1024^2 (FD 5-point + spectral residual on the same inputs)',
+                      value=value, unit='residual-updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                      ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                      dtype='f32' if args.fast else 'f32 fields; f64 forward FFT + f32 inverse FFT; f32 stencil',
+                      data='synthetic',
+                      config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral'
+                                           % (n, n, B, args.stencil),
+                                  grid=[n, n], batch_per_gpu=B, parallelism='batch-sharded x%d (no data-path collective)' % world,
+                                  inputs='Taylor-Green t=0.1 + band-limited noise, nu=2pi/1000, dt=1e-3, resident in HBM'),
+                      roofline=roofline)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            log('bench: timing the NumPy oracle on the host (bounded sample) ...')
+            result['cpu_baseline'] = cpu_baseline(n)
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

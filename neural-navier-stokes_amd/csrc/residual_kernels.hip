@@ -26,15 +26,19 @@ template <typename T> struct VecT;
 template <> struct VecT<float> { using type = float4; static constexpr int V = 4; };
 template <> struct VecT<double> { using type = double2; static constexpr int V = 2; };
 
+// Second differences (and the 9-point cross term) cancel O(1) values down to O(h^2): in float32 the
+// rounding of those sums, multiplied by 1/h^2 ~ 3e4 at 1024^2, is what limits the residual to ~2e-5
+// rel-L2.  They are therefore accumulated in float64 (exact for float32 inputs) -- ~25 fp64 ops per
+// point, free under the HBM bound.  First differences and products stay in the field type.
 template <typename T>
-struct ResK { T inv_dt, inv_2dx, inv_2dy, inv_dx2, inv_dy2, inv_rho, nu, c9; };
+struct ResK { T inv_dt, inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2, c9; };
 
 template <typename T>
 inline ResK<T> make_resk(double dt, double dx, double dy, double rho, double nu) {
     ResK<T> k;
     k.inv_dt = (T)(1.0 / dt); k.inv_2dx = (T)(1.0 / (2 * dx)); k.inv_2dy = (T)(1.0 / (2 * dy));
-    k.inv_dx2 = (T)(1.0 / (dx * dx)); k.inv_dy2 = (T)(1.0 / (dy * dy)); k.inv_rho = (T)(1.0 / rho); k.nu = (T)nu;
-    k.c9 = (T)((dx * dx + dy * dy) / 12.0 / (dx * dx * dy * dy));
+    k.inv_dx2 = 1.0 / (dx * dx); k.inv_dy2 = 1.0 / (dy * dy); k.inv_rho = (T)(1.0 / rho); k.nu = (T)nu;
+    k.c9 = (dx * dx + dy * dy) / 12.0 / (dx * dx * dy * dy);
     return k;
 }
 
@@ -119,18 +123,18 @@ __global__ __launch_bounds__(256) void fd_residual_vec_kernel(const T* __restric
             const T ux = (un.v[e] - um.v[e]) * k.inv_2dx, uy = (ur - ul) * k.inv_2dy;
             const T vx = (vn.v[e] - vm.v[e]) * k.inv_2dx, vy = (vr - vl) * k.inv_2dy;
             const T px = (pn.v[e] - pm.v[e]) * k.inv_2dx, py = (pr - pl) * k.inv_2dy;
-            T lu = (un.v[e] - 2 * ucc + um.v[e]) * k.inv_dx2 + (ur - 2 * ucc + ul) * k.inv_dy2;
-            T lv = (vn.v[e] - 2 * vcc + vm.v[e]) * k.inv_dx2 + (vr - 2 * vcc + vl) * k.inv_dy2;
+            double lu = ((double)un.v[e] - 2.0 * ucc + (double)um.v[e]) * k.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * k.inv_dy2;
+            double lv = ((double)vn.v[e] - 2.0 * vcc + (double)vm.v[e]) * k.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * k.inv_dy2;
             if constexpr (STENCIL == 9) {
                 const T uml = e == 0 ? um.l : um.v[e > 0 ? e - 1 : 0], umr = e == V - 1 ? um.r : um.v[e < V - 1 ? e + 1 : 0];
                 const T unl = e == 0 ? un.l : un.v[e > 0 ? e - 1 : 0], unr = e == V - 1 ? un.r : un.v[e < V - 1 ? e + 1 : 0];
                 const T vml = e == 0 ? vm.l : vm.v[e > 0 ? e - 1 : 0], vmr = e == V - 1 ? vm.r : vm.v[e < V - 1 ? e + 1 : 0];
                 const T vnl = e == 0 ? vn.l : vn.v[e > 0 ? e - 1 : 0], vnr = e == V - 1 ? vn.r : vn.v[e < V - 1 ? e + 1 : 0];
-                lu += k.c9 * ((uml + umr + unl + unr) - 2 * (um.v[e] + un.v[e] + ul + ur) + 4 * ucc);
-                lv += k.c9 * ((vml + vmr + vnl + vnr) - 2 * (vm.v[e] + vn.v[e] + vl + vr) + 4 * vcc);
+                lu += k.c9 * (((double)uml + umr + unl + unr) - 2.0 * ((double)um.v[e] + un.v[e] + ul + ur) + 4.0 * ucc);
+                lv += k.c9 * (((double)vml + vmr + vnl + vnr) - 2.0 * ((double)vm.v[e] + vn.v[e] + vl + vr) + 4.0 * vcc);
             }
-            o_u[e] = (ucc - upv[e]) * k.inv_dt + ucc * ux + vcc * uy + px * k.inv_rho - k.nu * lu;
-            o_v[e] = (vcc - vpv[e]) * k.inv_dt + ucc * vx + vcc * vy + py * k.inv_rho - k.nu * lv;
+            o_u[e] = (ucc - upv[e]) * k.inv_dt + ucc * ux + vcc * uy + px * k.inv_rho - k.nu * (T)lu;
+            o_v[e] = (vcc - vpv[e]) * k.inv_dt + ucc * vx + vcc * vy + py * k.inv_rho - k.nu * (T)lv;
             o_d[e] = ux + vy;
         }
         if (valid) { store_vec<T>(ru + rc, o_u); store_vec<T>(rv + rc, o_v); store_vec<T>(rd + rc, o_d); }
@@ -156,15 +160,15 @@ __global__ __launch_bounds__(256) void fd_residual_generic_kernel(const T* __res
     const T ux = (ue - uw) * k.inv_2dx, uy = (ur - ul) * k.inv_2dy;
     const T vx = (ve - vw) * k.inv_2dx, vy = (vr - vl) * k.inv_2dy;
     const T px = (at(p, in, j) - at(p, im, j)) * k.inv_2dx, py = (at(p, i, jn) - at(p, i, jm)) * k.inv_2dy;
-    T lu = (ue - 2 * ucc + uw) * k.inv_dx2 + (ur - 2 * ucc + ul) * k.inv_dy2;
-    T lv = (ve - 2 * vcc + vw) * k.inv_dx2 + (vr - 2 * vcc + vl) * k.inv_dy2;
+    double lu = ((double)ue - 2.0 * ucc + (double)uw) * k.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * k.inv_dy2;
+    double lv = ((double)ve - 2.0 * vcc + (double)vw) * k.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * k.inv_dy2;
     if constexpr (STENCIL == 9) {
-        lu += k.c9 * ((at(u, im, jm) + at(u, im, jn) + at(u, in, jm) + at(u, in, jn)) - 2 * (uw + ue + ul + ur) + 4 * ucc);
-        lv += k.c9 * ((at(v, im, jm) + at(v, im, jn) + at(v, in, jm) + at(v, in, jn)) - 2 * (vw + ve + vl + vr) + 4 * vcc);
+        lu += k.c9 * (((double)at(u, im, jm) + at(u, im, jn) + at(u, in, jm) + at(u, in, jn)) - 2.0 * ((double)uw + ue + ul + ur) + 4.0 * ucc);
+        lv += k.c9 * (((double)at(v, im, jm) + at(v, im, jn) + at(v, in, jm) + at(v, in, jn)) - 2.0 * ((double)vw + ve + vl + vr) + 4.0 * vcc);
     }
     const size_t c = g + (size_t)i * ny + j;
-    ru[c] = (ucc - up[c]) * k.inv_dt + ucc * ux + vcc * uy + px * k.inv_rho - k.nu * lu;
-    rv[c] = (vcc - vp[c]) * k.inv_dt + ucc * vx + vcc * vy + py * k.inv_rho - k.nu * lv;
+    ru[c] = (ucc - up[c]) * k.inv_dt + ucc * ux + vcc * uy + px * k.inv_rho - k.nu * (T)lu;
+    rv[c] = (vcc - vp[c]) * k.inv_dt + ucc * vx + vcc * vy + py * k.inv_rho - k.nu * (T)lv;
     rd[c] = ux + vy;
 }
 

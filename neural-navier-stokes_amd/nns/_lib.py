@@ -6,6 +6,11 @@ import of any op raises with build instructions -- it never degrades to NumPy/Py
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64: it must be loaded BEFORE libnns_hip.so so that both share ONE HIP
+# runtime (the SONAME libamdhip64.so.7 then resolves to the copy already mapped); loading ours first
+# binds a second runtime that sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libnns_hip.so')
 NNS_MAX_BC = 8
