@@ -15,8 +15,7 @@
 // and scatters y[s] to  (j / NS)*NS*R + (j mod NS) + s*NS.  With 16 elements per lane a lane plays
 // 16/R virtual threads j = tid + TPF*q, and the elements it needs are exactly the 16 it owns.
 // The last pass (NS*R == N) scatters back onto the same lane: no exchange.
-// LDS exchange image: element e at slot e + e/16 (one pad slot per 16) -- the stride-16 scatter of
-// the first pass then hits distinct banks for b64 and b128 stores alike.
+// LDS exchange image: element e at slot e + e/16 (see fft_slot).
 //
 // Twiddles W_N^k = exp(-2 pi i k / N) come from a half table (k < N/2, sign flip above) kept in
 // LDS, one table per arithmetic type in use.
@@ -103,7 +102,12 @@ __device__ __forceinline__ void dftR(C2<T> (&y)[R]) {
     else dft16<T, INV>(y);
 }
 
-__device__ __forceinline__ int fft_slot(int e) { return e + (e >> 4); }      // padded LDS slot of element e
+// LDS slot of element e in the exchange image: one pad slot per 16 elements.  The first pass scatters with
+// stride 16 (lane j writes 16j + t -> slot 17j + t: distinct banks for b64 and b128 stores), the read-back is
+// contiguous across lanes; every address is a per-lane base plus an immediate.  (An XOR swizzle
+// e ^ ((e>>4)&15) removes the residual 2-way conflict of the b128 read-back but costs ~250 extra integer
+// instructions per line; measured equal on MI355X -- the kernel is issue-bound, not LDS-bound.)
+__device__ __forceinline__ int fft_slot(int e) { return e + (e >> 4); }
 template <int N> struct FftGeom {
     static constexpr int TPF = N / 16;             // lanes per line
     static constexpr int SLOTS = N + N / 16;       // padded line length in the exchange image
@@ -123,20 +127,46 @@ __device__ __forceinline__ C2<T> twiddle(const C2<T>* __restrict__ tab, int k) {
 // image in LDS.  After a non-final pass x again holds elements tid + TPF*m of the partially
 // transformed sequence.
 template <typename T, int N, int R, int NS, bool INV>
-__device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict__ tab, C2<T>* __restrict__ xb, int tid) {
+__device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict__ tab, const C2<T>* __restrict__ tab2,
+                                         C2<T>* __restrict__ xb, int tid_in) {
     constexpr int TPF = N / 16, NB = 16 / R;
     constexpr bool LAST = (NS * R == N);
+    // Everything below that depends only on the lane id (twiddle indices, table and exchange addresses) is
+    // "free-floating" for instruction selection, which computes it thousands of instructions early and then
+    // spills it.  Tie the lane id to this pass's input data so the index math is emitted HERE.
+    int tid = tid_in;
+    asm volatile("" : "+v"(tid), "+v"(x[0].x));
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         const int j = tid + TPF * q;
         C2<T> y[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) y[t] = x[q + NB * t];
-        if constexpr (NS > 1) {
-            const int jm = (j & (NS - 1)) * (N / (NS * R));
+        if constexpr (NS == 16) {
+            // second pass: twiddle W_N^{t * c * N/(16 R)}, c = j mod 16, from the pass-2 table laid out [t][c]:
+            // for a given t the lanes of a wave read 16 CONSECUTIVE entries (conflict-free, broadcast across
+            // the lane groups that share c); striding the main table by t*c*N/(16R) was up to 16-way conflicted.
+            const int c = j & 15;
             if constexpr (sizeof(T) == 8) {
                 // float64: ONE table read, the other R-2 twiddles by running product (14 roundings of
                 // 1e-16 are irrelevant here, and 15 hoisted double2 reads would cost 60 VGPRs)
+                C2<T> w = tab2[16 + c];
+                if constexpr (INV) w.y = -w.y;
+                C2<T> wt = w;
+                y[1] = cmul<T>(y[1], wt);
+#pragma unroll
+                for (int t = 2; t < R; ++t) { wt = cmul<T>(wt, w); y[t] = cmul<T>(y[t], wt); }
+            } else {
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    C2<T> w = tab2[16 * t + c];
+                    if constexpr (INV) w.y = -w.y;
+                    y[t] = cmul<T>(y[t], w);
+                }
+            }
+        } else if constexpr (NS > 1) {
+            const int jm = (j & (NS - 1)) * (N / (NS * R));
+            if constexpr (sizeof(T) == 8) {
                 const C2<T> w = twiddle<T, N, INV>(tab, jm);
                 C2<T> wt = w;
                 y[1] = cmul<T>(y[1], wt);
@@ -169,16 +199,17 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
 
 // Full transform (unnormalised).  In and out: x[m] = element tid + TPF*m, natural order.
 template <typename T, int N, bool INV>
-__device__ __forceinline__ void fft_line(C2<T> (&x)[16], const C2<T>* __restrict__ tab, C2<T>* __restrict__ xb, int tid) {
+__device__ __forceinline__ void fft_line(C2<T> (&x)[16], const C2<T>* __restrict__ tab, const C2<T>* __restrict__ tab2,
+                                         C2<T>* __restrict__ xb, int tid) {
     static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024, "supported line lengths");
-    fft_pass<T, N, 16, 1, INV>(x, tab, xb, tid);
+    fft_pass<T, N, 16, 1, INV>(x, tab, tab2, xb, tid);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (N / 16 < 16) {
-        fft_pass<T, N, N / 16, 16, INV>(x, tab, xb, tid);
+        fft_pass<T, N, N / 16, 16, INV>(x, tab, tab2, xb, tid);
     } else {
-        fft_pass<T, N, 16, 16, INV>(x, tab, xb, tid);
+        fft_pass<T, N, 16, 16, INV>(x, tab, tab2, xb, tid);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (N / 256 > 1) fft_pass<T, N, N / 256, 256, INV>(x, tab, xb, tid);
+        if constexpr (N / 256 > 1) fft_pass<T, N, N / 256, 256, INV>(x, tab, tab2, xb, tid);
     }
 }
 
@@ -190,6 +221,20 @@ __device__ __forceinline__ void fill_twiddles(C2<T>* tab, int tid, int nthreads)
         sincospi(2.0 * (double)k / (double)N, &s, &c);
         tab[k].x = (T)c;
         tab[k].y = (T)(-s);
+    }
+}
+
+// Pass-2 table: tab2[16*t + c] = W_N^{t * c * N/(16*R2)}, t < R2 = min(16, N/16), c < 16.
+template <int N> struct Pass2 { static constexpr int R2 = (N / 16 < 16) ? N / 16 : 16; static constexpr int ENTRIES = 16 * R2; };
+template <typename T, int N>
+__device__ __forceinline__ void fill_twiddles2(C2<T>* tab2, int tid, int nthreads) {
+    constexpr int R2 = Pass2<N>::R2;
+    for (int e = tid; e < 16 * R2; e += nthreads) {
+        const int t = e >> 4, c = e & 15;
+        double s, co;
+        sincospi(2.0 * (double)(t * c * (N / (16 * R2))) / (double)N, &s, &co);
+        tab2[e].x = (T)co;
+        tab2[e].y = (T)(-s);
     }
 }
 

@@ -55,8 +55,8 @@ struct SpecLds {
     static constexpr int SKEW_DW = 32 / SKEW_MOD;                       // so a 32-lane store group hits 32 banks
     static constexpr int STAGE_BYTES = 3 * STAGE_F * 4 + 128;
     static constexpr int LINE_BYTES = ((XB_BYTES > STAGE_BYTES ? XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
-    static constexpr int TABF_BYTES = (N / 2) * (int)sizeof(C2<TF>);
-    static constexpr int TABI_BYTES = sizeof(TF) == 4 ? 0 : (N / 2) * (int)sizeof(C2<float>);
+    static constexpr int TABF_BYTES = (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<TF>);     // main half table + pass-2 table
+    static constexpr int TABI_BYTES = sizeof(TF) == 4 ? 0 : (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<float>);
     static constexpr int TOTAL = TABF_BYTES + TABI_BYTES + LINES * LINE_BYTES;
 };
 
@@ -77,18 +77,24 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
                                            const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid,
                                            const SpecK& k) {
     constexpr int TPF = N / 16;
+    const C2<TF>* tabF2 = tabF + N / 2;
+    const C2<float>* tabI2 = tabI + N / 2;
     C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);
     C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
     C2<TF> z[16];
     // ---- pressure: Z2 = FFT(p); keep only its contribution to b, already scaled, in float
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
-    fft_line<TF, N, false>(z, tabF, xbF, tid);
-    __builtin_amdgcn_sched_barrier(0);          // phases are independent: keep the scheduler from overlapping them
+    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    // The per-element wavenumber factors depend only on the lane id: left alone, instruction selection
+    // computes all 16 (fp64) during the butterflies above and spills them.  Tie the lane id to the
+    // transform's output so they are computed here, where they are used.
+    int te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         int ko, ke;
-        wavenumber<N>(tid + TPF * m, ko, ke);
+        wavenumber<N>(te + TPF * m, ko, ke);
         const TF s = (TF)((double)ko * k.kscale * k.inv_rho * k.inv_n);
         if constexpr (P_IN_REAL) { b[m].x = (float)(-s * z[m].y); b[m].y = (float)(s * z[m].x); }   // (i k/rho) Z2
         else { b[m].x = (float)(-s * z[m].x); b[m].y = (float)(-s * z[m].y); }                       // i (i k/rho) Z2
@@ -97,12 +103,13 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     // ---- velocity: Z1 = FFT(u + i v)
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)uf[m]; z[m].y = (TF)vf[m]; }
-    fft_line<TF, N, false>(z, tabF, xbF, tid);
-    __builtin_amdgcn_sched_barrier(0);
+    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         int ko, ke;
-        wavenumber<N>(tid + TPF * m, ko, ke);
+        wavenumber<N>(te + TPF * m, ko, ke);
         const TF k1 = (TF)((double)ko * k.kscale * k.inv_n);
         const double kk = (double)ke * k.kscale;
         const TF k2 = (TF)(k.nu * kk * kk * k.inv_n);
@@ -111,9 +118,9 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     }
     // ---- inverse transforms in float32
     __builtin_amdgcn_sched_barrier(0);
-    fft_line<float, N, true>(a, tabI, xbI, tid);
+    fft_line<float, N, true>(a, tabI, tabI2, xbI, tid);
     __builtin_amdgcn_sched_barrier(0);
-    fft_line<float, N, true>(b, tabI, xbI, tid);
+    fft_line<float, N, true>(b, tabI, tabI2, xbI, tid);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -122,11 +129,13 @@ __device__ __forceinline__ void spec_setup(unsigned char* smem, C2<TF>*& tabF, C
     using L = SpecLds<N, TF>;
     tabF = reinterpret_cast<C2<TF>*>(smem);
     fill_twiddles<TF, N>(tabF, threadIdx.x, kSpecThreads);
+    fill_twiddles2<TF, N>(tabF + N / 2, threadIdx.x, kSpecThreads);
     if constexpr (sizeof(TF) == 4) {
         tabI = reinterpret_cast<C2<float>*>(smem);
     } else {
         tabI = reinterpret_cast<C2<float>*>(smem + L::TABF_BYTES);
         fill_twiddles<float, N>(tabI, threadIdx.x, kSpecThreads);
+        fill_twiddles2<float, N>(tabI + N / 2, threadIdx.x, kSpecThreads);
     }
     lines = smem + L::TABF_BYTES + L::TABI_BYTES;
     __syncthreads();
@@ -147,12 +156,14 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
     spec_setup<N, TF>(smem, tabF, tabI, lines);
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int sub = lane / TPF, tid = lane % TPF;
-    const int line = wave * L::FPW + sub;
-    unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
     const long niter = (nrows + L::LINES - 1) / L::LINES;
     for (long it = blockIdx.x; it < niter; it += gridDim.x) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        const int line = wave * L::FPW + sub;
+        unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
         const long row_raw = it * L::LINES + line;
         const bool valid = row_raw < nrows;
         const long row = valid ? row_raw : nrows - 1;
@@ -161,19 +172,29 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
         int tidv = tid;
         asm volatile("" : "+v"(tidv));
         const size_t base = (size_t)row * N + tidv;
-        float uf[16], vf[16], pf[16];
+        // Memory phases are batched so that a line costs TWO exposed HBM round trips (prologue, epilogue), each
+        // with all of its loads in flight, instead of one per element: the r_* arrays are read and written
+        // through the same pointers, so an interleaved load/compute/store loop is serialised by the compiler.
+        float uf[16], vf[16], pf[16], du[16], dv[16];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) { uf[m] = u[base + TPF * m]; vf[m] = v[base + TPF * m]; pf[m] = p[base + TPF * m]; }
+        for (int m = 0; m < 16; ++m) {
+            uf[m] = u[base + TPF * m]; vf[m] = v[base + TPF * m]; pf[m] = p[base + TPF * m];
+            du[m] = up[base + TPF * m]; dv[m] = vp[base + TPF * m];
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { du[m] = (uf[m] - du[m]) * k.inv_dt; dv[m] = (vf[m] - dv[m]) * k.inv_dt; }
         C2<float> a[16], b[16];
         deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k);
+        float pu[16], pv[16], pd[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { pu[m] = ru[base + TPF * m]; pv[m] = rv[base + TPF * m]; pd[m] = rd[base + TPF * m]; }
         if (valid) {
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const size_t c = base + TPF * m;
-                const float uu = u[c], vv = v[c];                 // L2-hot re-read instead of 32 live VGPRs
-                ru[c] = (uu - up[c]) * k.inv_dt + ru[c] + vv * a[m].x + b[m].x;
-                rv[c] = (vv - vp[c]) * k.inv_dt + rv[c] + vv * a[m].y + b[m].y;
-                rd[c] = rd[c] + a[m].y;
+                ru[c] = du[m] + pu[m] + vf[m] * a[m].x + b[m].x;
+                rv[c] = dv[m] + pv[m] + vf[m] * a[m].y + b[m].y;
+                rd[c] = pd[m] + a[m].y;
             }
         }
     }
@@ -183,7 +204,9 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
 // x-pass: columns.  A workgroup owns LINES adjacent columns of one grid; the tile is staged
 // through LDS so that global accesses are row pieces of LINES*4 bytes.
 // ------------------------------------------------------------------------------------------
-template <int N, typename TF>
+// PREFETCH = false falls back to loading each tile at the top of its own iteration (instantiations whose
+// register allocation does not fit the extra 48 staging registers without spilling).
+template <int N, typename TF, bool PREFETCH>
 __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                                    const float* __restrict__ p, float* __restrict__ ru,
                                                                    float* __restrict__ rv, float* __restrict__ rd,
@@ -191,33 +214,60 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
     using L = SpecLds<N, TF>;
     constexpr int TPF = L::TPF, CW = L::LINES, SF = L::STAGE_F;
     constexpr int ROWS_PER_IT = kSpecThreads / CW;
+    constexpr int NR = N / ROWS_PER_IT;                 // staged elements per thread and field (= 16 for every N)
+    static_assert(NR == 16, "staging geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
     spec_setup<N, TF>(smem, tabF, tabI, lines);
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int sub = lane / TPF, tid = lane % TPF;
-    const int line = wave * L::FPW + sub;
-    unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
-    float* my_stage = reinterpret_cast<float*>(xb) + (line % L::SKEW_MOD) * L::SKEW_DW;   // skewed: conflict-free staging
-    // cooperative-copy role of this thread: column cc of the tile, rows cr + ROWS_PER_IT*i
-    const int cc = threadIdx.x % CW, cr = threadIdx.x / CW;
-    float* cp_stage = reinterpret_cast<float*>(lines + (size_t)cc * L::LINE_BYTES) + (cc % L::SKEW_MOD) * L::SKEW_DW;
 
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const long lt = xcd_remap((unsigned)t, (unsigned)ntiles);            // neighbouring tiles -> same XCD (shared lines)
-        const int b = (int)(lt / tiles_per_grid), tile = (int)(lt % tiles_per_grid);
-        const int j0 = tile * CW;
-        const size_t g = (size_t)b * N * ny;
-        const bool col_ok = j0 + cc < ny;
-        // ---- stage u, v, p columns: global row pieces -> LDS [line][field][row]
-        for (int r = cr; r < N; r += ROWS_PER_IT) {
-            const size_t c = g + (size_t)r * ny + j0 + cc;
-            cp_stage[0 * SF + r] = col_ok ? u[c] : 0.f;
-            cp_stage[1 * SF + r] = col_ok ? v[c] : 0.f;
-            cp_stage[2 * SF + r] = col_ok ? p[c] : 0.f;
+    // Software pipeline over tiles (issue early / write late): the raw u, v, p of tile t+1 are loaded into
+    // registers (su, sv, sp) while tile t is being transformed and are written to the LDS staging image only
+    // after the transforms have released it -- global-load latency hides under the FFT phase.
+    float su[NR], sv[NR], sp[NR];
+    auto tile_coords = [&](long t, int& j0, size_t& g) {
+        const long lt = xcd_remap((unsigned)t, (unsigned)ntiles);          // neighbouring tiles -> same XCD (shared lines)
+        j0 = (int)(lt % tiles_per_grid) * CW;
+        g = (size_t)(lt / tiles_per_grid) * N * ny;
+    };
+    auto issue_loads = [&](long t) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int cc = tx % CW, cr = tx / CW;
+        int j0; size_t g;
+        tile_coords(t, j0, g);
+        const bool ok = j0 + cc < ny;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const size_t c = g + (size_t)(cr + ROWS_PER_IT * i) * ny + j0 + cc;
+            su[i] = ok ? u[c] : 0.f; sv[i] = ok ? v[c] : 0.f; sp[i] = ok ? p[c] : 0.f;
+        }
+    };
+    long t = blockIdx.x;
+    if (PREFETCH && t < ntiles) issue_loads(t);
+    for (; t < ntiles; t += gridDim.x) {
+        if (!PREFETCH) issue_loads(t);
+        // thread-constant indices are recomputed per tile from an opaque copy of the thread id: cheaper than the
+        // spill/reload the compiler otherwise chooses for values that are live across the whole tile body
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        const int line = wave * L::FPW + sub;
+        unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
+        float* my_stage = reinterpret_cast<float*>(xb) + (line % L::SKEW_MOD) * L::SKEW_DW;   // skewed: conflict-free staging
+        int j0; size_t g;
+        tile_coords(t, j0, g);
+        {   // ---- staged registers -> LDS [line][field][row]
+            const int cc = tx % CW, cr = tx / CW;
+            float* cp_stage = reinterpret_cast<float*>(lines + (size_t)cc * L::LINE_BYTES) + (cc % L::SKEW_MOD) * L::SKEW_DW;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = cr + ROWS_PER_IT * i;
+                cp_stage[0 * SF + r] = su[i]; cp_stage[1 * SF + r] = sv[i]; cp_stage[2 * SF + r] = sp[i];
+            }
         }
         __syncthreads();
-        int tidv = tid;                                  // opaque per iteration: see the y-pass
+        int tidv = tid;
         asm volatile("" : "+v"(tidv));
         float uf[16], vf[16], pf[16];
 #pragma unroll
@@ -226,6 +276,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (PREFETCH && t + gridDim.x < ntiles) issue_loads(t + gridDim.x);  // prefetch the next tile (in flight during the FFTs)
         C2<float> a[16], b2[16];
         deriv_core<N, TF, true>(uf, vf, pf, a, b2, tabF, tabI, xb, tidv, k);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -237,12 +288,20 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
             my_stage[2 * SF + tidv + TPF * m] = a[m].x;                       // P_d = u_x
         }
         __syncthreads();
-        if (col_ok) {
-            for (int r = cr; r < N; r += ROWS_PER_IT) {
-                const size_t c = g + (size_t)r * ny + j0 + cc;
-                ru[c] = cp_stage[0 * SF + r];
-                rv[c] = cp_stage[1 * SF + r];
-                rd[c] = cp_stage[2 * SF + r];
+        {
+            int ty = threadIdx.x;
+            asm volatile("" : "+v"(ty));
+            const int cc2 = ty % CW, cr2 = ty / CW;
+            const float* st = reinterpret_cast<const float*>(lines + (size_t)cc2 * L::LINE_BYTES) + (cc2 % L::SKEW_MOD) * L::SKEW_DW;
+            if (j0 + cc2 < ny) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int r = cr2 + ROWS_PER_IT * i;
+                    const size_t c = g + (size_t)r * ny + j0 + cc2;
+                    ru[c] = st[0 * SF + r];
+                    rv[c] = st[1 * SF + r];
+                    rd[c] = st[2 * SF + r];
+                }
             }
         }
         __syncthreads();
@@ -254,7 +313,9 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
     using L = SpecLds<N, TF>;
     const int tiles_per_grid = (ny + L::LINES - 1) / L::LINES;
     const long ntiles = (long)batch * tiles_per_grid;
-    auto kern = spec_xpass_kernel<N, TF>;
+    // prefetch is disabled where hipcc (ROCm 7.2) spills with it: checked with -Rpass-analysis=kernel-resource-usage
+    constexpr bool PF = !((N == 128 && sizeof(TF) == 4) || N == 256);
+    auto kern = spec_xpass_kernel<N, TF, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
