@@ -100,6 +100,10 @@ def main():
     ap.add_argument('--stencil', type=int, default=5)
     ap.add_argument('--fast', action='store_true', help='all-float32 spectral path (2e-4 rel-L2) instead of the precise one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['batch', 'slab'], default='batch',
+                    help="batch: every rank owns --batch whole grids, no collective (weak scaling, default); "
+                         "slab: the SAME --batch grids are slab-decomposed by rows over the ranks -- RCCL halo "
+                         "send/recv for the stencil, 2 all-to-alls per spectral evaluation (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -125,14 +129,25 @@ def main():
     if rank == 0:
         log('bench: device', _lib.device_info(), 'world', world)
         log('bench: generating %d distinct %dx%d grids on the host ...' % (min(args.distinct, B), n, n))
-    f = make_inputs(B, n, args.distinct, 1234 + 1000 * rank, device)
+    slab = args.mode == 'slab' and world > 1
+    f = make_inputs(B, n, args.distinct, 1234 + (0 if slab else 1000 * rank), device)
     eng = ResidualEngine(n, n, dt, rho, nu, L, L, backend='spectral', precise=not args.fast)
-    out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
-    out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
+    if slab:
+        from nns.slab import SlabResidual
+        nloc = n // world
+        f = [t[:, rank * nloc:(rank + 1) * nloc].contiguous() for t in f]          # this rank's rows of every grid
+        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=not args.fast)
 
-    def step():
-        eng.fd(*f, stencil=args.stencil, out=out_fd)
-        eng.spectral(*f, out=out_sp)
+        def step():
+            sl.fd(*f, stencil=args.stencil)
+            sl.spectral(*f)
+    else:
+        out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
+        out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
+
+        def step():
+            eng.fd(*f, stencil=args.stencil, out=out_fd)
+            eng.spectral(*f, out=out_sp)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -154,9 +169,13 @@ def main():
         elapsed = float(t.item())
 
     pts = float(B) * n * n
-    value = world * pts * args.steps / elapsed
+    value = (1 if slab else world) * pts * args.steps / elapsed          # slab: the ranks share ONE batch of grids
 
     result = None
+    if slab:                                   # per-kernel roofline is measured on whole grids: rebuild local full-size inputs
+        f = make_inputs(B, n, args.distinct, 1234, device) if rank == 0 else f
+        out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
+        out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
     if rank == 0:
         # per-kernel durations, live, for the roofline object (same process, same inputs)
         iters = max(5, args.steps)
@@ -181,12 +200,12 @@ def main():
                                              achieved_GBs=BYTES_PER_PT[k] * pts / (v * 1e-3) / 1e9) for k, v in kt.items()})
         result = dict(metric='grid-point residual-updates/sec at 1024^2 (FD 5-point + spectral residual on the same inputs)',
                       value=value, unit='residual-updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                      ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                      ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong' if slab else 'weak', vs_baseline=None,
                       dtype='f32' if args.fast else 'f32 fields; f64 forward FFT + f32 inverse FFT; f32 stencil',
                       data='synthetic',
                       config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral'
                                            % (n, n, B, args.stencil),
-                                  grid=[n, n], batch_per_gpu=B, parallelism='batch-sharded x%d (no data-path collective)' % world,
+                                  grid=[n, n], batch_per_gpu=B, parallelism=('row-slab x%d: RCCL halo send/recv + 2 all-to-all per spectral eval' % world) if slab else 'batch-sharded x%d (no data-path collective)' % world,
                                   inputs='Taylor-Green t=0.1 + band-limited noise, nu=2pi/1000, dt=1e-3, resident in HBM'),
                       roofline=roofline)
     if dist is not None:

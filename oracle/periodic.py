@@ -99,3 +99,28 @@ def taylor_green(nx, ny, t, nu, rho=1.0, Lx=2 * np.pi, Ly=2 * np.pi):
     v = -np.sin(X) * np.cos(Y) * F
     p = -rho / 4. * (np.cos(2 * X) + np.cos(2 * Y)) * F * F
     return u, v, p
+
+
+def spectral_xpart(u, v, p, Lx, rho, nu):
+    """x-direction part of the spectral residual (what the HIP x-pass leaves in r_u, r_v, r_div):
+    P_u = u u_x + p_x/rho - nu u_xx,  P_v = u v_x - nu v_xx,  P_d = u_x."""
+    nx = u.shape[-2]
+    k1, k = wavenumbers(nx, Lx)
+    def d(f, mult):
+        return np.fft.ifft(np.fft.fft(f.astype(np.float64), axis=-2) * mult[:, None], axis=-2).real
+    ux, vx, px = d(u, 1j * k1), d(v, 1j * k1), d(p, 1j * k1)
+    uxx, vxx = d(u, -(k * k)), d(v, -(k * k))
+    return u * ux + px / rho - nu * uxx, u * vx - nu * vxx, ux
+
+
+def spectral_ypart(u, v, p, u_prev, v_prev, pu, pv, pd, dt, Ly, rho, nu):
+    """y-direction completion: r_u = (u-u_prev)/dt + P_u + v u_y - nu u_yy, etc."""
+    ny = u.shape[-1]
+    k1, k = wavenumbers(ny, Ly)
+    def d(f, mult):
+        return np.fft.ifft(np.fft.fft(f.astype(np.float64), axis=-1) * mult, axis=-1).real
+    uy, vy, py = d(u, 1j * k1), d(v, 1j * k1), d(p, 1j * k1)
+    uyy, vyy = d(u, -(k * k)), d(v, -(k * k))
+    r_u = (u - u_prev) / dt + pu + v * uy - nu * uyy
+    r_v = (v - v_prev) / dt + pv + v * vy + py / rho - nu * vyy
+    return r_u, r_v, pd + vy

@@ -161,3 +161,26 @@ def test_full_size_properties_1024_batch64(gpu_device):
         for a, b, c in zip(r64, r64b, r4):
             assert torch.equal(a, b)                                      # run-to-run bitwise
             assert torch.equal(a[:4], c) and torch.equal(a[60:], c)       # grid b of the batch == grid alone
+
+
+def test_slab_residual_single_rank_uses_hip_backend(gpu_device):
+    """nns.slab.SlabResidual with its default (HIP) compute back-end on one rank: the P == 1 path does the
+    same packing / padding / transposes locally, so the result must equal the direct ops."""
+    import torch.distributed as dist
+    from nns import ops
+    from nns.slab import SlabResidual
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29917', rank=0, world_size=1)
+        created = True
+    try:
+        f = [dev(a) for a in inputs(3, 128)]
+        s = SlabResidual(128, 128, DT, RHO, NU, L, L)
+        h = L / 128
+        for a, b in zip(s.fd(*f, stencil=9), ops.fd_residual(*f, DT, h, h, RHO, NU, 9)):
+            assert torch.equal(a, b)
+        for a, b in zip(s.spectral(*f), ops.spec_residual(*f, DT, L, L, RHO, NU)):
+            assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()
