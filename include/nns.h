@@ -165,6 +165,39 @@ int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, 
                                 const float* v_prev, float* r_u, float* r_v, float* r_div,
                                 int batch, int nx, int ny, double dt, double Ly,
                                 double rho, double nu, int precise, void* stream);
+
+/* ---- neural_spectral field predictor: src/neural_spectral/spectral_ode.py, anode/ ------------ */
+enum { NNS_ODE_EULER = 0, NNS_ODE_RK2 = 1, NNS_ODE_RK4 = 2 };   /* anode/scheme.py:21-42 */
+/* ODEFunc (spectral_ode.py:14-34: Linear(K,hidden)-ReLU-Linear(hidden,hidden)-ELU-Linear(hidden,K), torch
+ * nn.Linear layout W [out][in]) integrated by odesolver (anode/odesolver.py:21-37, time_stepper.py:35-45):
+ * dt = 1/Nt, out[n] = y_{n+1} for n = 0..Nt-1, out is [Nt, mb, K].  One persistent kernel: weights resident
+ * in LDS, linears on f32-input MFMA.  hidden must be 128, K <= 32. */
+int nns_ode_mlp_fwd_f32(const float* z0, const float* W0, const float* b0, const float* W1, const float* b1,
+                        const float* W2, const float* b2, float* out, int mb, int K, int hidden, int Nt,
+                        int method, void* stream);
+/* Backward of the above (what Checkpointing_Adjoint.backward computes, anode/adjoint.py:52-70, by
+ * recomputation): given states = the forward's out and grad_out [Nt, mb, K], writes grad_z0 [mb, K] and the six
+ * parameter gradients (zeroed and accumulated inside the call).  work: nns_ode_mlp_bwd_workspace(mb) bytes. */
+size_t nns_ode_mlp_bwd_workspace(int mb);
+int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b0, const float* W1, const float* b1,
+                        const float* W2, const float* b2, const float* states, const float* grad_out,
+                        float* grad_z0, float* gW0, float* gb0, float* gW1, float* gb1, float* gW2, float* gb2,
+                        void* work, int mb, int K, int hidden, int Nt, int method, void* stream);
+/* Basis expansion (PDEFunc.forward, spectral_ode.py:71-79): pred[t][c][p] = sum_k coeff[t][k][c] basis[k][c][p];
+ * coeff [T, K, C] (T = nt*mb), basis [K, C, P] (P = nx*ny), pred [T, C, P].  K <= 32. */
+int nns_basis_expand_f32(const float* coeff, const float* basis, float* pred, int T, int K, int C, int P, void* stream);
+/* Backward of nns_basis_expand_f32 for an arbitrary upstream gradient grad_pred [T, C, P]: gcoeff [T, K, C]
+ * (zeroed inside, atomics), gbasis [K, C, P]. */
+int nns_basis_expand_bwd_f32(const float* coeff, const float* basis, const float* grad_pred, float* gcoeff,
+                             float* gbasis, int T, int K, int C, int P, void* stream);
+/* Fused training loss (spectral_ode.py:182, torch.norm(pred - obs, 2)): accumulates sum (pred-obs)^2 into the
+ * device double *sumsq (caller zeroes it; loss = sqrt) without materialising pred; obs is read once. */
+int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const float* obs, double* sumsq,
+                           int T, int K, int C, int P, void* stream);
+/* Its gradients for g = scale * (pred - obs): gcoeff [T, K, C] (zeroed inside, atomics) and gbasis [K, C, P]. */
+int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* obs, float scale,
+                           float* gcoeff, float* gbasis, int T, int K, int C, int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

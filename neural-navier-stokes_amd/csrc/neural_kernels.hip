@@ -1,0 +1,514 @@
+// neural_spectral field predictor on gfx950:
+//   * ODEFunc MLP (src/neural_spectral/spectral_ode.py:14-34: Linear(K,128)-ReLU-Linear(128,128)-ELU-Linear(128,K))
+//     integrated with the ANODE fixed-step schemes (src/neural_spectral/anode/scheme.py:21-42,
+//     time_stepper.py:35-45: dt = 1/Nt, all Nt states returned) -- ONE persistent kernel per call instead of
+//     12 tiny GEMM launches per RK4 step: the three weight matrices live in LDS for the whole integration and
+//     the linears run on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in / f32 accumulate, bit-for-bit an
+//     fmaf chain, so float32 semantics are kept);
+//   * its backward, hand-written: like ANODE's "checkpointing adjoint" (anode/adjoint.py:52-70) it RECOMPUTES
+//     each step's stages from the stored states and back-propagates through them; weight gradients are
+//     accumulated in MFMA accumulators across all steps and stages and written once;
+//   * basis expansion u(x,y,t) = sum_k w_k(t) f_k(x,y) (spectral_ode.py:71-79), the Frobenius loss (:182) and
+//     their gradients, fused so the [nt, mb, 3, nx, ny] prediction is never materialised for training.
+//
+// A workgroup (4 waves) owns a tile of 16 batch rows (rows beyond mb are zero padding; gradients of padding
+// rows are zero by construction).  MFMA operand maps (cdna_hip_programming.md section 3, 16x16x4 f32):
+//   A: lane l holds A[row = l&15][k = l>>4],  B: lane l holds B[k = l>>4][col = l&15],
+//   C/D: lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
+#include "nns_common.h"
+
+using namespace nns;
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int H = 128;            // hidden width of ODEFunc (fixed in the reference)
+constexpr int KP = 32;            // padded coefficient count (K <= 32: K = 3 * n_coeffs = 30 in the reference driver)
+constexpr int HS = 132;           // LDS row stride of [*][128] images (pad 4: A-fragment reads 2-way at worst)
+constexpr int KS = 36;            // LDS row stride of [*][KP] images
+constexpr int TB = 16;            // batch rows per workgroup
+constexpr int NT = 256;           // threads per workgroup (4 waves)
+
+enum { METHOD_EULER = 0, METHOD_RK2 = 1, METHOD_RK4 = 2 };
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// D[16 x 16] += A[16 x Kd] * B[Kd x 16]:  A row-major [16][lda] (LDS), B row-major [Kd][ldb] at column n0
+__device__ __forceinline__ f32x4 mma_ab(const float* A, int lda, const float* B, int ldb, int n0, int Kd, f32x4 acc, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    for (int k0 = 0; k0 < Kd; k0 += 4) acc = mfma4(A[r * lda + k0 + q], B[(k0 + q) * ldb + n0 + r], acc);
+    return acc;
+}
+// D[16 x 16] += A[16 x Kd] * Bt^T with Bt row-major [>= c0+16][ldb]:  B[k][col] = Bt[c0 + col][k]
+__device__ __forceinline__ f32x4 mma_abt(const float* A, int lda, const float* Bt, int ldb, int c0, int Kd, f32x4 acc, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    for (int k0 = 0; k0 < Kd; k0 += 4) acc = mfma4(A[r * lda + k0 + q], Bt[(c0 + r) * ldb + k0 + q], acc);
+    return acc;
+}
+// D[16 x 16] += At^T * B over the 16 batch rows: D[i][n] = sum_b At[b][i0 + i] * B[b][n0 + n]
+__device__ __forceinline__ f32x4 mma_atb(const float* At, int lda, int i0, const float* B, int ldb, int n0, f32x4 acc, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < TB; k0 += 4) acc = mfma4(At[(k0 + q) * lda + i0 + r], B[(k0 + q) * ldb + n0 + r], acc);
+    return acc;
+}
+__device__ __forceinline__ void store_tile(float* D, int ldd, int n0, f32x4 acc, int lane) {
+    const int c = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[(r0 + r) * ldd + n0 + c] = acc[r];
+}
+
+struct MlpLds {                    // weights transposed to [in][out] (+ padding), resident for the whole kernel
+    float* Wt0;   // [KP][HS]
+    float* Wt1;   // [H][HS]
+    float* Wt2;   // [H][KS]
+    float* b0;    // [H]
+    float* b1;    // [H]
+    float* b2;    // [KP]
+};
+constexpr int kMlpFloats = KP * HS + H * HS + H * KS + 2 * H + KP;
+
+__device__ __forceinline__ float* carve(float*& p, int n) { float* r = p; p += (n + 3) & ~3; return r; }
+
+__device__ void load_mlp(MlpLds& m, float*& lds, const float* W0, const float* b0, const float* W1, const float* b1,
+                         const float* W2, const float* b2, int K, int tid) {
+    m.Wt0 = carve(lds, KP * HS); m.Wt1 = carve(lds, H * HS); m.Wt2 = carve(lds, H * KS);
+    m.b0 = carve(lds, H); m.b1 = carve(lds, H); m.b2 = carve(lds, KP);
+    for (int e = tid; e < KP * H; e += NT) { const int k = e / H, n = e % H; m.Wt0[k * HS + n] = k < K ? W0[n * K + k] : 0.f; }   // W0 [H][K]
+    for (int e = tid; e < H * H; e += NT) { const int n = e / H, k = e % H; m.Wt1[k * HS + n] = W1[n * H + k]; }                   // W1 [H][H]
+    for (int e = tid; e < KP * H; e += NT) { const int n = e / H, k = e % H; m.Wt2[k * KS + n] = n < K ? W2[n * H + k] : 0.f; }    // W2 [K][H]
+    for (int e = tid; e < H; e += NT) { m.b0[e] = b0[e]; m.b1[e] = b1[e]; }
+    for (int e = tid; e < KP; e += NT) m.b2[e] = e < K ? b2[e] : 0.f;
+}
+
+// F = MLP(S):  S [TB][KS] -> h1 [TB][HS] -> h2 [TB][HS] -> F [TB][KS].  Ends with a barrier.
+__device__ void mlp_eval(const MlpLds& m, const float* S, float* h1, float* h2, float* F, int wave, int lane) {
+    const int c = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                                           // layer 1: 8 column tiles, 2 per wave
+        const int n0 = 16 * (wave * 2 + t);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_ab(S, KS, m.Wt0, HS, n0, KP, acc, lane);
+        const float bb = m.b0[n0 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[(r0 + r) * HS + n0 + c] = fmaxf(acc[r] + bb, 0.f);             // ReLU
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                                           // layer 2
+        const int n0 = 16 * (wave * 2 + t);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_ab(h1, HS, m.Wt1, HS, n0, H, acc, lane);
+        const float bb = m.b1[n0 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float z = acc[r] + bb; h2[(r0 + r) * HS + n0 + c] = z > 0.f ? z : expm1f(z); }   // ELU(alpha = 1)
+    }
+    __syncthreads();
+    if (wave < KP / 16) {                                                   // layer 3: KP/16 column tiles
+        const int n0 = 16 * wave;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_ab(h2, HS, m.Wt2, KS, n0, H, acc, lane);
+        const float bb = m.b2[n0 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) F[(r0 + r) * KS + n0 + c] = acc[r] + bb;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: out[n] = y_{n+1}, n = 0..Nt-1
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void ode_mlp_fwd_kernel(const float* __restrict__ z0, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                         const float* __restrict__ W1, const float* __restrict__ b1,
+                                                         const float* __restrict__ W2, const float* __restrict__ b2,
+                                                         float* __restrict__ out, int mb, int K, int Nt, int method) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    MlpLds m;
+    load_mlp(m, lds, W0, b0, W1, b1, W2, b2, K, tid);
+    float* h1 = carve(lds, TB * HS); float* h2 = carve(lds, TB * HS);
+    float* Y = carve(lds, TB * KS); float* S = carve(lds, TB * KS); float* F = carve(lds, TB * KS); float* ACC = carve(lds, TB * KS);
+    const int row0 = blockIdx.x * TB;
+    for (int e = tid; e < TB * KS; e += NT) {
+        const int b = e / KS, k = e % KS;
+        const float v = (row0 + b < mb && k < K) ? z0[(size_t)(row0 + b) * K + k] : 0.f;
+        Y[e] = v; S[e] = v;
+    }
+    __syncthreads();
+    const float dt = 1.f / (float)Nt;
+    const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
+    const int nstage = method == METHOD_RK4 ? 4 : (method == METHOD_RK2 ? 2 : 1);
+    for (int n = 0; n < Nt; ++n) {
+        for (int s = 0; s < nstage; ++s) {
+            mlp_eval(m, S, h1, h2, F, wave, lane);
+            for (int e = tid; e < TB * KS; e += NT) {
+                const float k = dt * F[e], y = Y[e];
+                if (method == METHOD_EULER) { ACC[e] = y + k; }
+                else if (method == METHOD_RK2) { if (s == 0) S[e] = y + 0.5f * k; else ACC[e] = y + k; }
+                else {
+                    if (s == 0) { ACC[e] = y + c6 * k; S[e] = y + 0.5f * k; }
+                    else if (s == 1) { ACC[e] = ACC[e] + c3 * k; S[e] = y + 0.5f * k; }
+                    else if (s == 2) { ACC[e] = ACC[e] + c3 * k; S[e] = y + k; }
+                    else { ACC[e] = ACC[e] + c6 * k; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < TB * KS; e += NT) {
+            const int b = e / KS, k = e % KS;
+            const float y = ACC[e];
+            Y[e] = y; S[e] = y;
+            if (row0 + b < mb && k < K) out[((size_t)n * mb + row0 + b) * K + k] = y;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward.  work: per workgroup 4 stages x (S [TB][KS] + h1 [TB][HS] + h2 [TB][HS]) floats.
+// ------------------------------------------------------------------------------------------
+constexpr int kStageFloats = TB * KS + 2 * TB * HS;
+
+__global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict__ z0, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                         const float* __restrict__ W1, const float* __restrict__ b1,
+                                                         const float* __restrict__ W2, const float* __restrict__ b2,
+                                                         const float* __restrict__ states, const float* __restrict__ gout,
+                                                         float* __restrict__ gz0, float* __restrict__ gW0, float* __restrict__ gb0,
+                                                         float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
+                                                         float* __restrict__ gb2, float* __restrict__ work,
+                                                         int mb, int K, int Nt, int method) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    MlpLds m;
+    load_mlp(m, lds, W0, b0, W1, b1, W2, b2, K, tid);
+    float* BA = carve(lds, TB * HS); float* BB = carve(lds, TB * HS); float* BC = carve(lds, TB * HS);
+    float* Y = carve(lds, TB * KS); float* S = carve(lds, TB * KS); float* F = carve(lds, TB * KS);
+    float* GY = carve(lds, TB * KS); float* GF = carve(lds, TB * KS); float* GS = carve(lds, TB * KS);
+    float* GK0 = carve(lds, TB * KS); float* GK1 = carve(lds, TB * KS); float* GK2 = carve(lds, TB * KS);
+    float* A = carve(lds, TB * KS);
+    float* ws = work + (size_t)blockIdx.x * 4 * kStageFloats;
+    const int row0 = blockIdx.x * TB;
+    const float dt = 1.f / (float)Nt;
+    const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
+    const int nstage = method == METHOD_RK4 ? 4 : (method == METHOD_RK2 ? 2 : 1);
+
+    // weight-gradient accumulators (transposed [in][out] tiles), persistent across steps and stages:
+    // gWt1: 8x8 tiles -> wave owns (i-tile it, n-tile nt) with (it*8+nt) % 4 == wave: 16 tiles; gWt0: 2x8 -> 4; gWt2: 8x2 -> 4.
+    f32x4 aW1[16], aW0[4], aW2[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { aW0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; aW2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float ab0 = 0.f, ab1 = 0.f, ab2 = 0.f;               // bias gradients: thread tid < H owns column tid (tid < KP for b2)
+
+    for (int e = tid; e < TB * KS; e += NT) A[e] = 0.f;
+    __syncthreads();
+
+    for (int n = Nt - 1; n >= 0; --n) {
+        // adjoint of y_{n+1} += grad of output n; y_n = z0 (n == 0) or states[n-1]
+        for (int e = tid; e < TB * KS; e += NT) {
+            const int b = e / KS, k = e % KS;
+            const bool ok = row0 + b < mb && k < K;
+            A[e] += ok ? gout[((size_t)n * mb + row0 + b) * K + k] : 0.f;
+            const float y = !ok ? 0.f : (n == 0 ? z0[(size_t)(row0 + b) * K + k] : states[((size_t)(n - 1) * mb + row0 + b) * K + k]);
+            Y[e] = y; S[e] = y;
+        }
+        __syncthreads();
+        // ---- recompute the stages, saving stage inputs and activations
+        for (int s = 0; s < nstage; ++s) {
+            mlp_eval(m, S, BA, BB, F, wave, lane);
+            float* w = ws + (size_t)s * kStageFloats;
+            for (int e = tid; e < TB * KS; e += NT) w[e] = S[e];
+            for (int e = tid; e < TB * HS; e += NT) { w[TB * KS + e] = BA[e]; w[TB * KS + TB * HS + e] = BB[e]; }
+            if (s + 1 < nstage) {
+                for (int e = tid; e < TB * KS; e += NT) {
+                    const float k = dt * F[e], y = Y[e];
+                    S[e] = (method == METHOD_RK4 && s == 2) ? y + k : y + 0.5f * k;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- output adjoints of the stage increments k_s
+        for (int e = tid; e < TB * KS; e += NT) {
+            const float a = A[e];
+            GY[e] = a;
+            if (method == METHOD_RK4) { GK0[e] = c6 * a; GK1[e] = c3 * a; GK2[e] = c3 * a; GF[e] = dt * (c6 * a); }   // GF = dt * gk4
+            else if (method == METHOD_RK2) { GK0[e] = 0.f; GF[e] = dt * a; }                                          // y' = y + k2
+            else { GF[e] = dt * a; }
+        }
+        __syncthreads();
+        for (int s = nstage - 1; s >= 0; --s) {
+            const float* w = ws + (size_t)s * kStageFloats;
+            for (int e = tid; e < TB * KS; e += NT) S[e] = w[e];
+            for (int e = tid; e < TB * HS; e += NT) { BA[e] = w[TB * KS + e]; BB[e] = w[TB * KS + TB * HS + e]; }      // h1, h2
+            __syncthreads();
+            // layer 3 backward: gWt2[k][n] += h2^T GF ; gb2 += colsum GF ; gh2 = GF W2 -> gz2 = gh2 * elu'(z2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const int tile = wave + 4 * t, it = tile / 2, nt = tile % 2; aW2[t] = mma_atb(BB, HS, 16 * it, GF, KS, 16 * nt, aW2[t], lane); }
+            if (tid < KP) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += GF[b * KS + tid]; ab2 += sacc; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k0 = 16 * (wave * 2 + t);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mma_abt(GF, KS, m.Wt2, KS, k0, KP, acc, lane);            // gh2[b][k] = sum_n GF[b][n] Wt2[k][n]
+                const int c = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float h = BB[(r0 + r) * HS + k0 + c]; BC[(r0 + r) * HS + k0 + c] = acc[r] * (h > 0.f ? 1.f : h + 1.f); }
+            }
+            __syncthreads();
+            // layer 2 backward: gWt1 += h1^T gz2 ; gb1 += colsum gz2 ; gh1 = gz2 W1 -> gz1 = gh1 * relu'(z1)   (into BB)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8; aW1[t] = mma_atb(BA, HS, 16 * it, BC, HS, 16 * nt, aW1[t], lane); }
+            if (tid < H) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += BC[b * HS + tid]; ab1 += sacc; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k0 = 16 * (wave * 2 + t);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mma_abt(BC, HS, m.Wt1, HS, k0, H, acc, lane);             // gh1[b][k] = sum_n gz2[b][n] Wt1[k][n]
+                const int c = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float h = BA[(r0 + r) * HS + k0 + c]; BB[(r0 + r) * HS + k0 + c] = h > 0.f ? acc[r] : 0.f; }
+            }
+            __syncthreads();
+            // layer 1 backward: gWt0 += S^T gz1 ; gb0 += colsum gz1 ; GS = gz1 W0
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8; aW0[t] = mma_atb(S, KS, 16 * it, BB, HS, 16 * nt, aW0[t], lane); }
+            if (tid < H) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += BB[b * HS + tid]; ab0 += sacc; }
+            if (wave < KP / 16) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mma_abt(BB, HS, m.Wt0, HS, 16 * wave, H, acc, lane);      // GS[b][k] = sum_n gz1[b][n] Wt0[k][n]
+                store_tile(GS, KS, 16 * wave, acc, lane);
+            }
+            __syncthreads();
+            // ---- scheme bookkeeping: gy += GS; pass GS on to the previous stage's increment; next GF
+            for (int e = tid; e < TB * KS; e += NT) {
+                const float g = GS[e];
+                GY[e] += g;
+                if (method == METHOD_RK4) {
+                    if (s == 3) { GK2[e] += g; GF[e] = dt * GK2[e]; }                 // S4 = y + k3
+                    else if (s == 2) { GK1[e] += 0.5f * g; GF[e] = dt * GK1[e]; }     // S3 = y + k2/2
+                    else if (s == 1) { GK0[e] += 0.5f * g; GF[e] = dt * GK0[e]; }     // S2 = y + k1/2
+                } else if (method == METHOD_RK2) {
+                    if (s == 1) { GK0[e] += 0.5f * g; GF[e] = dt * GK0[e]; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < TB * KS; e += NT) A[e] = GY[e];
+        __syncthreads();
+    }
+    // ---- results: grad z0, and the weight/bias gradients (atomics: several batch tiles may contribute)
+    for (int e = tid; e < TB * KS; e += NT) {
+        const int b = e / KS, k = e % KS;
+        if (row0 + b < mb && k < K) gz0[(size_t)(row0 + b) * K + k] = A[e];
+    }
+    const int c = lane & 15, r0 = 4 * (lane >> 4);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {                          // gW1[n][k] = gWt1[k][n]
+        const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&gW1[(size_t)(16 * nt + c) * H + 16 * it + r0 + r], aW1[t][r]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                           // gW0[n][k] (k < K) = gWt0[k][n]
+        const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int k = 16 * it + r0 + r; if (k < K) atomicAdd(&gW0[(size_t)(16 * nt + c) * K + k], aW0[t][r]); }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                           // gW2[n][k] (n < K) = gWt2[k][n]
+        const int tile = wave + 4 * t, it = tile / 2, nt = tile % 2;
+        const int nn = 16 * nt + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (nn < K) atomicAdd(&gW2[(size_t)nn * H + 16 * it + r0 + r], aW2[t][r]);
+    }
+    if (tid < H) { atomicAdd(&gb0[tid], ab0); atomicAdd(&gb1[tid], ab1); }
+    if (tid < K) atomicAdd(&gb2[tid], ab2);
+}
+
+constexpr size_t kFwdLds = (size_t)(kMlpFloats + 2 * TB * HS + 4 * TB * KS + 64) * sizeof(float);
+constexpr size_t kBwdLds = (size_t)(kMlpFloats + 3 * TB * HS + 10 * TB * KS + 64) * sizeof(float);
+
+int method_id(int method) { return (method >= 0 && method <= 2) ? method : -1; }
+
+// ------------------------------------------------------------------------------------------
+// basis expansion, loss, gradients.   coeff [T][K][C], basis [K][C][P], obs / pred [T][C][P]
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxK = 32;
+
+// pred[t][c][p] = sum_k coeff[t][k][c] * basis[k][c][p]      (materialising form, PDEFunc.forward)
+__global__ __launch_bounds__(256) void basis_expand_kernel(const float* __restrict__ coeff, const float* __restrict__ basis,
+                                                           float* __restrict__ pred, int T, int K, int C, int P) {
+    __shared__ float cw[kMaxK];
+    const int t = blockIdx.y, c = blockIdx.z;
+    if (threadIdx.x < K) cw[threadIdx.x] = coeff[((size_t)t * K + threadIdx.x) * C + c];
+    __syncthreads();
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(cw[k], basis[((size_t)k * C + c) * P + p], acc);
+        pred[((size_t)t * C + c) * P + p] = acc;
+    }
+}
+
+// Fused loss / gradient pass.  A workgroup owns (channel c, a tile of 256*PPT pixels) and walks all T time
+// rows: the K basis values of its pixels stay in registers, obs is streamed ONCE (4 B per element -- the
+// compulsory traffic), pred is never written.  MODE 0: sumsq += (pred-obs)^2.  MODE 2: g is READ from `obs`
+// (generic upstream gradient of the materialised prediction).  MODE 1 (backward, g = scale * (pred - obs)): gbasis[k][c][p] = sum_t coeff[t][k][c] g  (registers, written once),
+//                gcoeff[t][k][c] += sum_p basis[k][c][p] g (wave reduction + one atomic per wave).
+template <int MODE>
+__global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict__ coeff, const float* __restrict__ basis,
+                                                         const float* __restrict__ obs, double* __restrict__ sumsq,
+                                                         float* __restrict__ gcoeff, float* __restrict__ gbasis, float scale,
+                                                         int T, int K, int C, int P, int TC) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* cw = reinterpret_cast<float*>(smem_raw);                  // [TC][K] coefficients of this channel, one chunk of time rows
+    const int c = blockIdx.y, tid = threadIdx.x, lane = tid % kWave;
+    const int p = blockIdx.x * 256 + tid;
+    const bool ok = p < P;
+    float fk[kMaxK], gb[kMaxK];
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) { fk[k] = (ok && k < K) ? basis[((size_t)k * C + c) * P + p] : 0.f; gb[k] = 0.f; }
+    double local = 0.0;
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tn = min(TC, T - t0);
+        __syncthreads();
+        for (int e = tid; e < tn * K; e += 256) cw[e] = coeff[((size_t)t0 * K + e) * C + c];
+        __syncthreads();
+        for (int tt = 0; tt < tn; ++tt) {
+            const int t = t0 + tt;
+            float pred = 0.f;
+            if (MODE != 2) {
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k) if (k < K) pred = fmaf(cw[tt * K + k], fk[k], pred);
+            }
+            const float ob = ok ? obs[((size_t)t * C + c) * P + p] : 0.f;
+            const float r = MODE == 2 ? ob : (ok ? pred - ob : 0.f);
+            if (MODE == 0) { local += (double)r * (double)r; }
+            else {
+                const float g = MODE == 2 ? r : scale * r;
+#pragma unroll
+                for (int k = 0; k < kMaxK; ++k) {
+                    if (k < K) {
+                        gb[k] = fmaf(cw[tt * K + k], g, gb[k]);
+                        float s = fk[k] * g;
+                        for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_down(s, o);
+                        if (lane == 0) atomicAdd(&gcoeff[((size_t)t * K + k) * C + c], s);
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_down(local, o);
+        if (lane == 0) atomicAdd(sumsq, local);
+    } else if (ok) {
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) if (k < K) gbasis[((size_t)k * C + c) * P + p] = gb[k];
+    }
+}
+
+}  // namespace
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+NNS_API size_t nns_ode_mlp_bwd_workspace(int mb) {
+    if (mb < 1) return 0;
+    return (size_t)((mb + TB - 1) / TB) * 4 * kStageFloats * sizeof(float);
+}
+
+NNS_API int nns_ode_mlp_fwd_f32(const float* z0, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                const float* b2, float* out, int mb, int K, int hidden, int Nt, int method, void* stream) {
+    if (!z0 || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !out || mb < 1 || Nt < 1) return fail(NNS_ERR_INVALID_ARG, "ode_mlp_fwd: bad args");
+    if (hidden != H) return fail(NNS_ERR_UNSUPPORTED, "ode_mlp_fwd: hidden width %d (the reference's ODEFunc is fixed at %d)", hidden, H);
+    if (K < 1 || K > KP) return fail(NNS_ERR_UNSUPPORTED, "ode_mlp_fwd: K=%d not in [1, %d]", K, KP);
+    if (method_id(method) < 0) return fail(NNS_ERR_INVALID_ARG, "ode_mlp_fwd: method %d (0 Euler, 1 RK2, 2 RK4)", method);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ode_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(ode_mlp_fwd_kernel, dim3((mb + TB - 1) / TB), dim3(NT), kFwdLds, S(stream), z0, W0, b0, W1, b1, W2, b2, out, mb, K, Nt, method);
+    return check_launch("ode_mlp_fwd");
+}
+
+NNS_API int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                const float* b2, const float* states, const float* grad_out, float* grad_z0, float* gW0, float* gb0,
+                                float* gW1, float* gb1, float* gW2, float* gb2, void* work, int mb, int K, int hidden, int Nt, int method,
+                                void* stream) {
+    if (!z0 || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !states || !grad_out || !grad_z0 || !gW0 || !gb0 || !gW1 || !gb1 || !gW2 || !gb2 || !work ||
+        mb < 1 || Nt < 1)
+        return fail(NNS_ERR_INVALID_ARG, "ode_mlp_bwd: bad args");
+    if (hidden != H) return fail(NNS_ERR_UNSUPPORTED, "ode_mlp_bwd: hidden width %d (fixed at %d)", hidden, H);
+    if (K < 1 || K > KP) return fail(NNS_ERR_UNSUPPORTED, "ode_mlp_bwd: K=%d not in [1, %d]", K, KP);
+    if (method_id(method) < 0) return fail(NNS_ERR_INVALID_ARG, "ode_mlp_bwd: method %d", method);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ode_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipStream_t s = S(stream);
+    // the parameter gradients are accumulated with atomics: zero them first (stream-ordered memset nodes)
+    hipError_t e = hipMemsetAsync(gW0, 0, (size_t)H * K * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(gb0, 0, H * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(gW1, 0, (size_t)H * H * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(gb1, 0, H * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(gW2, 0, (size_t)K * H * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(gb2, 0, K * sizeof(float), s);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_mlp_bwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(ode_mlp_bwd_kernel, dim3((mb + TB - 1) / TB), dim3(NT), kBwdLds, s, z0, W0, b0, W1, b1, W2, b2, states, grad_out,
+                       grad_z0, gW0, gb0, gW1, gb1, gW2, gb2, reinterpret_cast<float*>(work), mb, K, Nt, method);
+    return check_launch("ode_mlp_bwd");
+}
+
+NNS_API int nns_basis_expand_f32(const float* coeff, const float* basis, float* pred, int T, int K, int C, int P, void* stream) {
+    if (!coeff || !basis || !pred || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_expand: bad args");
+    if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_expand: K=%d > %d", K, kMaxK);
+    if (T > 65535 || C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_expand: T, C must be <= 65535");
+    int gx = (P + 255) / 256; if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(basis_expand_kernel, dim3(gx, T, C), dim3(256), 0, S(stream), coeff, basis, pred, T, K, C, P);
+    return check_launch("basis_expand");
+}
+
+// sumsq (a device double) is ACCUMULATED into: the caller zeroes it (loss = sqrt(sumsq), spectral_ode.py:182).
+NNS_API int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const float* obs, double* sumsq, int T, int K, int C, int P, void* stream) {
+    if (!coeff || !basis || !obs || !sumsq || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_fwd: bad args");
+    if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fwd: K=%d > %d", K, kMaxK);
+    const int TC = T < (8192 / K) ? T : (8192 / K);                     // time rows per LDS coefficient chunk (<= 32 KB)
+    const size_t lds = (size_t)TC * K * sizeof(float);
+    if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fwd: C must be <= 65535");
+    hipLaunchKernelGGL(basis_loss_kernel<0>, dim3((P + 255) / 256, C), dim3(256), lds, S(stream), coeff, basis, obs, sumsq, nullptr, nullptr, 0.f, T, K, C, P, TC);
+    return check_launch("basis_loss_fwd");
+}
+
+// g = scale * (pred - obs) (scale = upstream / loss).  gcoeff [T][K][C] is zeroed here and accumulated with atomics; gbasis is overwritten.
+NNS_API int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* obs, float scale, float* gcoeff, float* gbasis,
+                                   int T, int K, int C, int P, void* stream) {
+    if (!coeff || !basis || !obs || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_bwd: bad args");
+    if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: K=%d > %d", K, kMaxK);
+    const int TC = T < (8192 / K) ? T : (8192 / K);                     // time rows per LDS coefficient chunk (<= 32 KB)
+    const size_t lds = (size_t)TC * K * sizeof(float);
+    if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: C must be <= 65535");
+    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_bwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(basis_loss_kernel<1>, dim3((P + 255) / 256, C), dim3(256), lds, S(stream), coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P, TC);
+    return check_launch("basis_loss_bwd");
+}
+
+// Backward of nns_basis_expand_f32 for an arbitrary upstream gradient grad_pred [T, C, P].
+NNS_API int nns_basis_expand_bwd_f32(const float* coeff, const float* basis, const float* grad_pred, float* gcoeff, float* gbasis,
+                                     int T, int K, int C, int P, void* stream) {
+    if (!coeff || !basis || !grad_pred || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_expand_bwd: bad args");
+    if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: K=%d > %d", K, kMaxK);
+    const int TC = T < (8192 / K) ? T : (8192 / K);
+    const size_t lds = (size_t)TC * K * sizeof(float);
+    if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: C must be <= 65535");
+    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_expand_bwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(basis_loss_kernel<2>, dim3((P + 255) / 256, C), dim3(256), lds, S(stream), coeff, basis, grad_pred, nullptr, gcoeff, gbasis, 1.f, T, K, C, P, TC);
+    return check_launch("basis_expand_bwd");
+}

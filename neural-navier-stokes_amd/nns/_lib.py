@@ -44,13 +44,20 @@ _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_xpass_f32': [_P] * 6 + [_I] * 3 + [_D] * 3 + [_I, _P],
     'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_ode_mlp_fwd_f32': [_P] * 8 + [_I] * 5 + [_P],
+    'nns_ode_mlp_bwd_f32': [_P] * 17 + [_I] * 5 + [_P],
+    'nns_ode_mlp_bwd_workspace': [_I],
+    'nns_basis_expand_f32': [_P] * 3 + [_I] * 4 + [_P],
+    'nns_basis_expand_bwd_f32': [_P] * 5 + [_I] * 4 + [_P],
+    'nns_basis_loss_fwd_f32': [_P] * 4 + [_I] * 4 + [_P],
+    'nns_basis_loss_bwd_f32': [_P] * 3 + [C.c_float] + [_P] * 2 + [_I] * 4 + [_P],
     'nns_fd_predictor_adi_workspace': [_I, _I, _I, _I],
     'nns_fd_sor_workspace': [_I, _I, _I, _I],
     'nns_device_info': [C.c_char_p, _I, C.POINTER(_I), C.POINTER(_SZ)],
     'nns_version': [],
     'nns_last_error': [],
 }
-_RESTYPES = {'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_last_error': C.c_char_p}
+_RESTYPES = {'nns_ode_mlp_bwd_workspace': _SZ, 'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_last_error': C.c_char_p}
 
 
 def exported_names():

@@ -1,0 +1,173 @@
+"""Mirror of the reference's ``src/neural_spectral/spectral_ode.py``: ``ODEFunc``, ``PDEFunc``, ``BasisFunc``,
+``AverageMeter`` with identical constructor arguments, parameter / state-dict names
+(``init_coeffs``, ``basis_coeffs.net.{0,2,4}.{weight,bias}``, ``basis_fns.{k}``), initialisation
+(weights ~ N(0, 0.1), biases 0, :28-31; coefficients and bases ~ N(0, 1), :53,:58) and forward semantics.
+
+u(x, y, t) = sum_k w_k(t) f_k(x, y)  (:62-81): the coefficient ODE runs as one fused RK4-MLP kernel, the
+expansion as one kernel; ``PDEFunc.loss`` is the fused training path (prediction never materialised).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .anode import odesolver_adjoint as odesolver
+
+
+class ODEFunc(nn.Module):
+    """Model basis coefficients as an ODE wrt time (spectral_ode.py:14-34)."""
+
+    def __init__(self, K):
+        super().__init__()
+        self.K = K
+        self.net = nn.Sequential(
+            nn.Linear(self.K, 128),
+            nn.ReLU(inplace=True),
+            nn.Linear(128, 128),
+            nn.ELU(inplace=True),
+            nn.Linear(128, self.K),
+        )
+        for m in self.net.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0, std=0.1)
+                nn.init.constant_(m.bias, val=0)
+
+    def forward(self, t, coeff):
+        return self.net(coeff)
+
+
+class _BasisExpandFn(torch.autograd.Function):
+    """pred[T, C, P] = sum_k coeff[T, K, C] * basis[K, C, P]"""
+
+    @staticmethod
+    def forward(ctx, coeff, basis):
+        coeff, basis = coeff.contiguous(), basis.contiguous()
+        ctx.save_for_backward(coeff, basis)
+        return ops.basis_expand(coeff, basis)
+
+    @staticmethod
+    def backward(ctx, g):
+        coeff, basis = ctx.saved_tensors
+        return ops.basis_expand_bwd(coeff, basis, g.contiguous())
+
+
+class _BasisLossFn(torch.autograd.Function):
+    """|| sum_k coeff basis - obs ||_2 (spectral_ode.py:182) without materialising the prediction."""
+
+    @staticmethod
+    def forward(ctx, coeff, basis, obs):
+        coeff, basis, obs = coeff.contiguous(), basis.contiguous(), obs.contiguous()
+        loss = torch.sqrt(ops.basis_loss_fwd(coeff, basis, obs)).to(torch.float32).reshape(())
+        ctx.save_for_backward(coeff, basis, obs, loss)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        coeff, basis, obs, loss = ctx.saved_tensors
+        scale = float((g / loss).item())
+        gc, gb = ops.basis_loss_bwd(coeff, basis, obs, scale)
+        return gc, gb, None
+
+
+def _device_path(*ts):
+    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+def expand(coeff, basis):
+    """coeff [T, K, C], basis [K, C, P] -> [T, C, P]; fused kernel on a HIP device, einsum elsewhere."""
+    if _device_path(coeff, basis) and coeff.shape[1] <= 32:
+        return _BasisExpandFn.apply(coeff, basis)
+    return torch.einsum('tkc,kcp->tcp', coeff, basis)
+
+
+class PDEFunc(nn.Module):
+    """u(x,y,t) = sum_k w_k(t) f_k(x,y)  (spectral_ode.py:37-97)."""
+
+    def __init__(self, K, nx, ny):
+        super().__init__()
+        self.K = K
+        self.nx, self.ny = nx, ny
+        self.init_coeffs = nn.Parameter(torch.normal(torch.zeros(self.K * 3), 1))
+        self.basis_coeffs = ODEFunc(self.K * 3)
+        self.basis_fns = nn.ParameterList([
+            nn.Parameter(torch.normal(torch.zeros(3, self.nx, self.ny), 1))
+            for _ in range(self.K)
+        ])
+
+    def _coeff(self, mb, nt):
+        coeff = odesolver(self.basis_coeffs, self.init_coeffs.unsqueeze(0).repeat(mb, 1), {'Nt': nt, 'method': 'RK4'})
+        return coeff.view(nt * mb, self.K, 3)                       # (:71) view(nt, mb, K, 3)
+
+    def _basis(self):
+        return torch.stack([f for f in self.basis_fns]).reshape(self.K, 3, self.nx * self.ny)
+
+    def forward(self, grid0, t):
+        # grid0 = mb x 3 x nx x ny (only its batch size is used, :67), t = nt (only its length is used)
+        mb, nt = grid0.size(0), t.size(0)
+        soln = expand(self._coeff(mb, nt), self._basis())
+        return soln.view(nt, mb, 3, self.nx, self.ny)
+
+    def loss(self, grid0, t, obs):
+        """Fused ``torch.norm(self(grid0, t) - obs, p=2)`` (the training objective, :181-182)."""
+        mb, nt = grid0.size(0), t.size(0)
+        coeff, basis = self._coeff(mb, nt), self._basis()
+        o = obs.reshape(nt * mb, 3, self.nx * self.ny)
+        if _device_path(coeff, basis, o) and self.K <= 32:
+            return _BasisLossFn.apply(coeff, basis, o)
+        return torch.norm(torch.einsum('tkc,kcp->tcp', coeff, basis) - o, p=2)
+
+    def basis_weight_mat(self):
+        W = []
+        for k in range(self.K):
+            theta = self.basis_fns[k].flatten()
+            W.append(theta)
+        return torch.stack(W)
+
+    def diversity_penalty(self):
+        W = self.basis_weight_mat()
+        penalty = 0
+        for i in range(0, self.K):
+            for j in range(i, self.K):
+                penalty = penalty + torch.norm(W[i] - W[j], p=2)
+        penalty = 1. / penalty
+        return penalty
+
+
+class BasisFunc(nn.Module):
+    """A basis to build up a function (spectral_ode.py:100-119): per-pixel MLP as 1x1 convolutions."""
+
+    def __init__(self, nx, ny):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.net = nn.Sequential(
+            nn.Conv2d(3, 16, 1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(16, 32, 1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(32, 32, 1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(32, 16, 1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(16, 3, 1),
+        )
+
+    def forward(self, grid):
+        return self.net(grid)
+
+
+class AverageMeter(object):
+    """Computes and stores the average and current value (spectral_ode.py:122-137)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count

@@ -183,3 +183,72 @@ def spec_residual_ypass_(u, v, p, u_prev, v_prev, ru, rv, rd, dt, Ly, rho, nu, p
     check(_lib.lib().nns_spec_residual_ypass_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
                                                  dt, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_ypass_f32')
     return ru, rv, rd
+
+
+# ----------------------------------------------------------------------------- neural_spectral
+ODE_METHODS = {'Euler': 0, 'RK2': 1, 'RK4': 2}
+
+
+def _f32(*ts):
+    for t in ts:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise TypeError("expected contiguous float32 CUDA/HIP tensors")
+
+
+def ode_mlp_fwd(z0, W0, b0, W1, b1, W2, b2, Nt, method):
+    _f32(z0, W0, b0, W1, b1, W2, b2)
+    mb, K = z0.shape
+    out = torch.empty(Nt, mb, K, dtype=torch.float32, device=z0.device)
+    check(_lib.lib().nns_ode_mlp_fwd_f32(_p(z0), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2), _p(out), mb, K, W1.shape[0],
+                                         int(Nt), ODE_METHODS[method], _stream()), 'nns_ode_mlp_fwd_f32')
+    return out
+
+
+def ode_mlp_bwd(z0, W0, b0, W1, b1, W2, b2, states, grad_out, Nt, method):
+    _f32(z0, W0, b0, W1, b1, W2, b2, states, grad_out)
+    mb, K = z0.shape
+    gz0 = torch.empty_like(z0)
+    gs = [torch.empty_like(t) for t in (W0, b0, W1, b1, W2, b2)]
+    work = torch.empty(_lib.lib().nns_ode_mlp_bwd_workspace(mb) // 4, dtype=torch.float32, device=z0.device)
+    check(_lib.lib().nns_ode_mlp_bwd_f32(_p(z0), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2), _p(states), _p(grad_out), _p(gz0),
+                                         *[_p(g) for g in gs], _p(work), mb, K, W1.shape[0], int(Nt), ODE_METHODS[method], _stream()),
+          'nns_ode_mlp_bwd_f32')
+    return gz0, gs
+
+
+def basis_expand(coeff, basis):
+    """coeff [T, K, C], basis [K, C, P] -> pred [T, C, P]"""
+    _f32(coeff, basis)
+    T, K, C = coeff.shape
+    P = basis.shape[2]
+    pred = torch.empty(T, C, P, dtype=torch.float32, device=coeff.device)
+    check(_lib.lib().nns_basis_expand_f32(_p(coeff), _p(basis), _p(pred), T, K, C, P, _stream()), 'nns_basis_expand_f32')
+    return pred
+
+
+def basis_expand_bwd(coeff, basis, grad_pred):
+    _f32(coeff, basis, grad_pred)
+    T, K, C = coeff.shape
+    P = basis.shape[2]
+    gc, gb = torch.empty_like(coeff), torch.empty_like(basis)
+    check(_lib.lib().nns_basis_expand_bwd_f32(_p(coeff), _p(basis), _p(grad_pred), _p(gc), _p(gb), T, K, C, P, _stream()), 'nns_basis_expand_bwd_f32')
+    return gc, gb
+
+
+def basis_loss_fwd(coeff, basis, obs):
+    """sum (pred - obs)^2 as a device float64 scalar tensor (pred never materialised)."""
+    _f32(coeff, basis, obs)
+    T, K, C = coeff.shape
+    P = basis.shape[2]
+    ss = torch.zeros(1, dtype=torch.float64, device=coeff.device)
+    check(_lib.lib().nns_basis_loss_fwd_f32(_p(coeff), _p(basis), _p(obs), _p(ss), T, K, C, P, _stream()), 'nns_basis_loss_fwd_f32')
+    return ss
+
+
+def basis_loss_bwd(coeff, basis, obs, scale):
+    _f32(coeff, basis, obs)
+    T, K, C = coeff.shape
+    P = basis.shape[2]
+    gc, gb = torch.empty_like(coeff), torch.empty_like(basis)
+    check(_lib.lib().nns_basis_loss_bwd_f32(_p(coeff), _p(basis), _p(obs), float(scale), _p(gc), _p(gb), T, K, C, P, _stream()), 'nns_basis_loss_bwd_f32')
+    return gc, gb
