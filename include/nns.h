@@ -198,6 +198,25 @@ int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const float* 
 int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* obs, float scale,
                            float* gcoeff, float* gbasis, int T, int K, int C, int P, void* stream);
 
+
+/* ---- chorin_spectral (Chebyshev collocation): src/chorin_spectral/simulate.py ---------------- */
+/* Row-major float64 GEMM on the matrix cores: C = alpha * op(A) op(B) + beta * C, op = transpose when the flag is
+ * set; `batch` independent problems stored back to back.  Replaces the `@` products of _predictor_step
+ * (:264-298) and _correction_step (:361-380). */
+int nns_cheb_gemm_f64(const double* A, int lda, int transA, const double* B, int ldb, int transB, double* C, int ldc,
+                      int M, int N, int K, double alpha, double beta, int batch, void* stream);
+/* F = 2 f - 3 dt (un fx + vn fy) + dt (un1 f1x + vn1 f1y) + dt (fxx + fyy), elementwise on n values (:277-282). */
+int nns_cheb_helmholtz_rhs_f64(const double* f, const double* un, const double* vn, const double* un1, const double* vn1,
+                               const double* fx, const double* fy, const double* f1x, const double* f1y,
+                               const double* fxx, const double* fyy, double* F, int n, double dt, void* stream);
+/* out[i][j] = Hm[i][j] / (c0 + cx * lam_x[i] + cy * lam_y[j])  (:287-288, :372-373). */
+int nns_cheb_diag_div_f64(const double* Hm, const double* lam_x, const double* lam_y, double* out, int ni, int nj,
+                          double c0, double cx, double cy, void* stream);
+/* full [Nx, Ny] = interior sol [(Nx-2), (Ny-2)] + boundary rows x0, xN [Ny-2] and columns y0, yN [Nx-2], corners 0
+ * (:322-334). */
+int nns_cheb_embed_f64(const double* sol, const double* x0, const double* xN, const double* y0, const double* yN,
+                       double* full, int Nx, int Ny, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

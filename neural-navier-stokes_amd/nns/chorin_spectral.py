@@ -1,0 +1,260 @@
+"""Chorin projection with Chebyshev Gauss-Lobatto collocation: mirror of the reference's
+``src/chorin_spectral/simulate.py`` ``NavierStokesSystem`` (same ctor -- note: NO ``p_bc`` -- same
+attribute names for the operator matrices, ``step``, ``simulate``, ``_predictor_step``,
+``_correction_step`` and the matrix helpers).
+
+One-time setup (matrix construction, ``eig`` / ``inv`` of (N-2)^2 matrices) stays on the host in NumPy /
+LAPACK exactly as in the reference (:59-199); the per-step work -- ~30 dense float64 matmuls and the
+elementwise assemblies -- runs on the GPU (csrc/cheb_kernels.hip: f64 MFMA GEMM + fused kernels).
+
+The reference's matrices are kept AS THEY ARE (``D @ D.T`` at :493, ``bar_c`` called with N at :470-471,
+sin arguments with N vs nodes with N-1): the reference is the spec, even where it is unsound (its
+trajectories diverge) -- use at operator level.  Differences, on purpose: the process-
+global ``warnings.filterwarnings('error')`` (:1-3) is not replicated; complex eigenvalues (N >= 52) raise
+FloatingPointError here instead of a ComplexWarning-turned-error.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._util import default_device
+
+
+def dup_vector_by_row(v, n):
+    return v[:, np.newaxis].repeat(n, axis=1)
+
+
+def dup_vector_by_col(v, n):
+    return dup_vector_by_row(v, n).T
+
+
+class NavierStokesSystem():
+    def __init__(self, u_ic, v_ic, p_ic, u_bc, v_bc, nt=200, nit=50,
+                 nx=50, ny=50, dt=0.001, rho=1, nu=1, beta=1.25, device=None):
+        self.u_ic, self.v_ic, self.p_ic = u_ic, v_ic, p_ic
+        self.u_bc, self.v_bc = u_bc, v_bc                      # no BC needed for pressure (:44)
+        self.nt, self.nit, self.dt, self.nx, self.ny = nt, nit, dt, nx, ny
+        self.dx, self.dy = 2. / self.nx, 2. / self.ny          # (:48)
+        self.rho, self.nu, self.beta = rho, nu, beta
+        self.device = device if device is not None else default_device()
+        self._pseudospectral_setup()
+
+    # ------------------------------------------------------------------ matrix helpers (:387-531)
+    def _get_c_k(self, k):
+        assert k >= 0
+        return 2 if k == 0 else 1
+
+    def _get_bar_c_k(self, k, N):
+        assert k >= 0
+        return 2 if (k == 0 or k == N) else 1
+
+    def _get_gauss_lobatto_points(self, N, k=1):
+        return np.cos(k * np.pi * np.arange(N) / float(N - 1))
+
+    def _get_T_matrix(self, N):
+        return np.stack([self._get_gauss_lobatto_points(N, k=k) for k in np.arange(0, N)])
+
+    def _get_inv_T_matrix(self, N):
+        inv_T = self._get_T_matrix(N).T
+        bar_c_i = np.stack([np.repeat(self._get_bar_c_k(i, N), N) for i in np.arange(0, N)])
+        return 2 * inv_T / (bar_c_i.T * bar_c_i * N)
+
+    def _get_D_matrix(self, N):
+        idx = np.arange(N)
+        i, j = idx[:, None].astype(np.float64), idx[None, :].astype(np.float64)
+        bc = np.array([self._get_bar_c_k(k, N) for k in range(N)], dtype=np.float64)
+        sign = np.where((idx[:, None] + idx[None, :]) % 2 == 0, 1.0, -1.0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            diff = 2 * np.sin((j + i) * np.pi / (2. * N)) * np.sin((j - i) * np.pi / (2. * N))
+            D = bc[:, None] / bc[None, :] * sign / diff
+        D[idx, idx] = 0.0
+        for r in range(N):
+            D[r, r] = -np.sum(D[r, :])
+        return D
+
+    def _get_D_sqr_matrix(self, N):
+        D = self._get_D_matrix(N)
+        D_sqr = (D @ D.T).copy()                               # FIXME in the reference (:493); kept
+        for r in range(N):
+            D_sqr[r, r] = -np.sum(D_sqr[r, :])                 # row sum still contains the old diagonal (:502)
+        return D_sqr
+
+    def _get_D_matrix_degrees_minus_2(self, N):
+        x = self._get_gauss_lobatto_points(N)
+        D = np.zeros((N, N))
+        for i in range(1, N - 1):
+            for j in range(1, N - 1):
+                if i != j:
+                    D[i, j] = ((-1) ** (j + 1) * (1. - x[j] ** 2) / ((1. - x[i] ** 2) * (x[i] - x[j])))
+                else:
+                    D[i, i] = 3 * x[i] / (2. * (1. - x[i] ** 2))
+        return D[1:-1, 1:-1]
+
+    def _process_boundary_conditions(self, bc_list):
+        vals = {}
+        names = {'left': 'minus_x', 'right': 'plus_x', 'top': 'minus_y', 'bottom': 'plus_y'}     # (:204-215)
+        for bc in bc_list:
+            if bc.type == 'dirichlet':
+                if bc.boundary not in names:
+                    raise Exception('Boundary side {} not supported'.format(bc.boundary))
+                vals['alpha_' + names[bc.boundary]] = 1
+                vals['g_' + names[bc.boundary]] = bc.value
+            elif bc.type == 'neumann':
+                raise NotImplementedError                       # (:218-221)
+            else:
+                raise Exception('Boundary type {} not supported'.format(bc.type))
+        for s in names.values():
+            vals['beta_' + s] = 0
+        return vals
+
+    @staticmethod
+    def _boundary_constants(D, bc, ax):
+        am, ap = bc['alpha_minus_' + ax], bc['alpha_plus_' + ax]
+        bm, bp = bc['beta_minus_' + ax], bc['beta_plus_' + ax]
+        c0_minus = -bp * D[0, -1]
+        c0_plus = am + bm * D[-1, -1]
+        cN_plus = -bm * D[-1, 0]
+        cN_minus = ap + bp * D[0, 0]
+        e = c0_plus * cN_minus - c0_minus * cN_plus
+        b0 = -c0_plus * bp * D[0, 1:-1] - c0_minus * bm * D[-1, 1:-1]
+        bN = -cN_minus * bm * D[-1, 1:-1] - cN_plus * bp * D[0, 1:-1]
+        return dict(e=e, c0_minus=c0_minus, c0_plus=c0_plus, cN_minus=cN_minus, cN_plus=cN_plus, b0=b0, bN=bN)
+
+    @staticmethod
+    def _real_eig(M, what):
+        lam, P = np.linalg.eig(M)
+        if np.iscomplexobj(lam) and np.abs(lam.imag).max() > 0:
+            raise FloatingPointError("chorin_spectral: complex eigenvalues in %s (the reference fails here too, for N >= 52)" % what)
+        return np.real(lam), np.real(P)
+
+    def _dev(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+
+    def _pseudospectral_setup(self):
+        Nx, Ny = self.nx, self.ny
+        self.x_i, self.y_i = self._get_gauss_lobatto_points(Nx), self._get_gauss_lobatto_points(Ny)
+        self.Tx, self.Ty = self._get_T_matrix(Nx), self._get_T_matrix(Ny)
+        self.Tx_inv, self.Ty_inv = self._get_inv_T_matrix(Nx), self._get_inv_T_matrix(Ny)
+        self.Dx, self.Dy = self._get_D_matrix(Nx), self._get_D_matrix(Ny)
+        self.Dx_sqr, self.Dy_sqr = self._get_D_sqr_matrix(Nx), self._get_D_sqr_matrix(Ny)
+        self._bc = {'u': self._process_boundary_conditions(self.u_bc), 'v': self._process_boundary_conditions(self.v_bc)}
+        self._k, self._helm = {}, {}
+        for f in ('u', 'v'):
+            kx = self._boundary_constants(self.Dx, self._bc[f], 'x')
+            ky = self._boundary_constants(self.Dy, self._bc[f], 'y')
+            self._k[f] = (kx, ky)
+            Mx = self.Dx_sqr[1:-1, 1:-1] + 1. / kx['e'] * (kx['b0'] * self.Dx_sqr[1:-1, 0] + kx['bN'] * self.Dx_sqr[1:-1, -1])
+            My = self.Dy_sqr[1:-1, 1:-1] + 1. / ky['e'] * (ky['b0'] * self.Dy_sqr[1:-1, 0] + ky['bN'] * self.Dy_sqr[1:-1, -1])
+            lx, P = self._real_eig(Mx, f + '_Dx')
+            ly, Q = self._real_eig(My, f + '_Dy')
+            for name, val in (('Dx_lambda', lx), ('Dx_P', P), ('Dy_lambda', ly), ('Dy_Q', Q),
+                              ('Dx_P_inv', np.linalg.inv(P)), ('Dy_Q_inv', np.linalg.inv(Q))):
+                setattr(self, '%s_%s' % (f, name), val)                     # reference attribute names (:174-183)
+            self._helm[f] = {k: self._dev(v) for k, v in dict(lx=lx, ly=ly, P=P, Q=Q, P_inv=np.linalg.inv(P), Q_inv=np.linalg.inv(Q)).items()}
+        self.DPx, self.DPy = self._get_D_matrix_degrees_minus_2(Nx), self._get_D_matrix_degrees_minus_2(Ny)
+        self.DxDPx = self.Dx[1:-1, 1:-1] @ self.DPx
+        self.DyDPy = self.Dy[1:-1, 1:-1] @ self.DPy
+        self.DxDPx_lambda, self.DxDPx_P = self._real_eig(self.DxDPx, 'DxDPx')
+        self.DyDPy_lambda, self.DyDPy_Q = self._real_eig(self.DyDPy, 'DyDPy')
+        self.DxDPx_P_inv, self.DyDPy_Q_inv = np.linalg.inv(self.DxDPx_P), np.linalg.inv(self.DyDPy_Q)
+        d = self._dev
+        self._D = dict(Dx=d(self.Dx[1:-1, 1:-1]), Dy=d(self.Dy[1:-1, 1:-1]), Dxx=d(self.Dx_sqr[1:-1, 1:-1]), Dyy=d(self.Dy_sqr[1:-1, 1:-1]),
+                       DxDPx=d(self.DxDPx), DyDPy=d(self.DyDPy), lpx=d(self.DxDPx_lambda), lpy=d(self.DyDPy_lambda),
+                       PP=d(self.DxDPx_P), PQ=d(self.DyDPy_Q), PP_inv=d(self.DxDPx_P_inv), PQ_inv=d(self.DyDPy_Q_inv))
+        # the correction step's boundary source S (:353-361) depends on the BC values only
+        gu, gv = self._bc['u'], self._bc['v']
+        u_tau = np.stack([np.ones(Ny - 2) * gu['g_minus_x'], np.ones(Ny - 2) * gu['g_plus_x']])
+        v_tau = np.stack([np.ones(Nx - 2) * gv['g_minus_y'], np.ones(Nx - 2) * gv['g_plus_y']]).T
+        Dx_bar = np.stack([self.Dx[1:-1, 0], self.Dx[1:-1, -1]]).T
+        Dy_bar = np.stack([self.Dy[1:-1, 0], self.Dy[1:-1, -1]]).T
+        self._S = d(-(Dx_bar @ u_tau + v_tau @ Dy_bar.T))
+
+    # ------------------------------------------------------------------ per-step operators on the GPU
+    def _boundary_vectors(self, sol, name):
+        """get_boundary_values (:245-256): with Dirichlet-only BCs b0 = bN = 0 and these are constants; the general
+        b0 / bN terms are kept as (1 x n) @ (n x n) GEMMs on the device."""
+        kx, ky = self._k[name]
+        g = self._bc[name]
+        ni, nj = sol.shape
+        def vec(b, const, n, left):
+            out = torch.full((n,), float(const), dtype=torch.float64, device=self.device)
+            if np.any(b != 0):
+                bt = self._dev(b[None, :] if left else b[:, None])
+                prod = ops.cheb_gemm(bt, sol) if left else ops.cheb_gemm(sol, bt)
+                out = out + prod.reshape(-1)
+            return out.contiguous()
+        x0 = vec(kx['b0'] / kx['e'], (kx['c0_minus'] * g['g_minus_x'] + kx['c0_plus'] * g['g_plus_x']) / kx['e'], nj, True)
+        xN = vec(kx['bN'] / kx['e'], 0.0, nj, True)
+        y0 = vec(ky['b0'] / ky['e'], (ky['c0_minus'] * g['g_minus_y'] + ky['c0_plus'] * g['g_plus_y']) / ky['e'], ni, False)
+        yN = vec(ky['bN'] / ky['e'], 0.0, ni, False)
+        return x0, xN, y0, yN
+
+    def _predict_dev(self, un, vn, un1, vn1):
+        D, mm = self._D, ops.cheb_gemm
+        I = lambda a: a[1:-1, 1:-1].contiguous()
+        _un, _vn, _un1, _vn1 = I(un), I(vn), I(un1), I(vn1)
+        out = []
+        for name, f, f1 in (('u', _un, _un1), ('v', _vn, _vn1)):
+            fx, fy = mm(D['Dx'], f), mm(f, D['Dy'], transB=True)                       # (:264-268)
+            f1x, f1y = mm(D['Dx'], f1), mm(f1, D['Dy'], transB=True)
+            fxx, fyy = mm(D['Dxx'], f), mm(f, D['Dyy'], transB=True)                   # (:270-274)
+            F = ops.cheb_helmholtz_rhs(f, _un, _vn, _un1, _vn1, fx, fy, f1x, f1y, fxx, fyy, self.dt)
+            h = self._helm[name]
+            Hh = mm(mm(h['P_inv'], F), h['Q_inv'], transB=True)                        # (:285-286)
+            hat = ops.cheb_diag_div(Hh, h['lx'], h['ly'], 2.0, -self.dt, -self.dt)     # (:287-288)
+            sol = mm(h['P'], mm(hat, h['Q'], transB=True))                             # (:289-290)
+            out.append(ops.cheb_embed(sol, *self._boundary_vectors(sol, name)))
+        return out[0], out[1]
+
+    def _correct_dev(self, ui, vi, p):
+        D, mm = self._D, ops.cheb_gemm
+        I = lambda a: a[1:-1, 1:-1].contiguous()
+        ui_i, vi_i = I(ui), I(vi)
+        Tm = self._S.clone()                                                           # S - Dx ui - vi Dy^T   (:367)
+        mm(D['Dx'], ui_i, alpha=-1.0, beta=1.0, out=Tm)
+        mm(vi_i, D['Dy'], transB=True, alpha=-1.0, beta=1.0, out=Tm)
+        Ht = mm(D['PP_inv'], Tm, alpha=-self.rho / self.dt)                            # H_tilde = PP_inv @ (-rho/dt * T)
+        Hh = mm(Ht, D['PQ_inv'], transB=True)
+        Qh = ops.cheb_diag_div(Hh, D['lpx'], D['lpy'], 0.0, 1.0, 1.0)                  # (:372-373)
+        Q = mm(D['PP'], mm(Qh, D['PQ'], transB=True))
+        u1, v1, p1 = ui.clone(), vi.clone(), p.clone()
+        mm(D['DxDPx'], Q, alpha=-self.dt / self.rho, beta=1.0, out=ui_i)               # (:379)
+        mm(Q, D['DyDPy'], transB=True, alpha=-self.dt / self.rho, beta=1.0, out=vi_i)  # (:380)
+        u1[1:-1, 1:-1] = ui_i
+        v1[1:-1, 1:-1] = vi_i
+        p1[1:-1, 1:-1] = Q
+        return u1, v1, p1
+
+    # ------------------------------------------------------------------ reference call surface
+    def _predictor_step(self, un, vn, un1, vn1):
+        ui, vi = self._predict_dev(*[self._dev(a) for a in (un, vn, un1, vn1)])
+        return ui.cpu().numpy(), vi.cpu().numpy()
+
+    def _correction_step(self, ui, vi, p):
+        a, b, c = self._correct_dev(self._dev(ui), self._dev(vi), self._dev(p))
+        return a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()
+
+    def step(self, un, vn, un1, vn1, p):
+        ui, vi = self._predict_dev(*[self._dev(a) for a in (un, vn, un1, vn1)])
+        a, b, c = self._correct_dev(ui, vi, self._dev(p))
+        return a.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()
+
+    def _init_variables(self):
+        from .boundary import apply_list
+        u, v, p = np.array(self.u_ic, dtype=np.float64), np.array(self.v_ic, dtype=np.float64), np.array(self.p_ic, dtype=np.float64)
+        apply_list(u, self.u_bc)
+        apply_list(v, self.v_bc)
+        return u, v, p
+
+    def simulate(self):
+        u, v, p = (self._dev(a) for a in self._init_variables())
+        u1, v1 = u.clone(), v.clone()
+        us, vs, ps = [], [], []
+        for n in range(self.nt):
+            ui, vi = self._predict_dev(u, v, u1, v1)
+            _u, _v, p = self._correct_dev(ui, vi, p)
+            u1, v1 = u, v
+            u, v = _u, _v
+            us.append(u), vs.append(v), ps.append(p)
+        f = lambda l: torch.stack(l).cpu().numpy()
+        return f(us), f(vs), f(ps)

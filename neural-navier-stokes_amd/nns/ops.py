@@ -252,3 +252,51 @@ def basis_loss_bwd(coeff, basis, obs, scale):
     gc, gb = torch.empty_like(coeff), torch.empty_like(basis)
     check(_lib.lib().nns_basis_loss_bwd_f32(_p(coeff), _p(basis), _p(obs), float(scale), _p(gc), _p(gb), T, K, C, P, _stream()), 'nns_basis_loss_bwd_f32')
     return gc, gb
+
+
+# ----------------------------------------------------------------------------- chorin_spectral
+def _f64(*ts):
+    for t in ts:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise TypeError("expected contiguous float64 CUDA/HIP tensors")
+
+
+def cheb_gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, out=None):
+    """Row-major 2-D float64: out = alpha * op(A) @ op(B) + beta * out."""
+    _f64(A, B)
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    if (B.shape[1] if transB else B.shape[0]) != K:
+        raise ValueError("cheb_gemm: inner dimensions differ")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float64, device=A.device)
+        beta = 0.0
+    _f64(out)
+    check(_lib.lib().nns_cheb_gemm_f64(_p(A), A.shape[1], int(transA), _p(B), B.shape[1], int(transB), _p(out), out.shape[1],
+                                       M, N, K, float(alpha), float(beta), 1, _stream()), 'nns_cheb_gemm_f64')
+    return out
+
+
+def cheb_helmholtz_rhs(f, un, vn, un1, vn1, fx, fy, f1x, f1y, fxx, fyy, dt):
+    _f64(f, un, vn, un1, vn1, fx, fy, f1x, f1y, fxx, fyy)
+    F = torch.empty_like(f)
+    check(_lib.lib().nns_cheb_helmholtz_rhs_f64(*[_p(t) for t in (f, un, vn, un1, vn1, fx, fy, f1x, f1y, fxx, fyy)], _p(F), f.numel(),
+                                                float(dt), _stream()), 'nns_cheb_helmholtz_rhs_f64')
+    return F
+
+
+def cheb_diag_div(Hm, lam_x, lam_y, c0, cx, cy):
+    _f64(Hm, lam_x, lam_y)
+    out = torch.empty_like(Hm)
+    check(_lib.lib().nns_cheb_diag_div_f64(_p(Hm), _p(lam_x), _p(lam_y), _p(out), Hm.shape[0], Hm.shape[1], float(c0), float(cx), float(cy),
+                                           _stream()), 'nns_cheb_diag_div_f64')
+    return out
+
+
+def cheb_embed(sol, x0, xN, y0, yN):
+    _f64(sol, x0, xN, y0, yN)
+    Nx, Ny = sol.shape[0] + 2, sol.shape[1] + 2
+    full = torch.empty(Nx, Ny, dtype=torch.float64, device=sol.device)
+    check(_lib.lib().nns_cheb_embed_f64(_p(sol), _p(x0), _p(xN), _p(y0), _p(yN), _p(full), Nx, Ny, _stream()), 'nns_cheb_embed_f64')
+    return full
