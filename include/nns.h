@@ -198,6 +198,13 @@ int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const float* 
 int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* obs, float scale,
                            float* gcoeff, float* gbasis, int T, int K, int C, int P, void* stream);
 
+/* Per-pixel MLP forward (BasisFunc, spectral_ode.py:100-119: a stack of 1x1 Conv2d with ReLU between layers,
+ * generalised to <= 8 layers of width <= 64): x [mb, widths[0], P] -> y [mb, widths[nlayers], P], P = nx*ny.
+ * weights / biases: the layers' [C_out][C_in] matrices and [C_out] vectors packed back to back (device);
+ * widths_host: nlayers+1 ints (host).  All layers are chained in MFMA accumulators (no LDS/HBM round trip
+ * between layers).  bf16 == 0: float32 MFMA (exact fp32); bf16 != 0: bfloat16 operands, float32 accumulate. */
+int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const float* biases, float* y, int mb, int P,
+                          const int* widths_host, int nlayers, int bf16, void* stream);
 
 /* ---- chorin_spectral (Chebyshev collocation): src/chorin_spectral/simulate.py ---------------- */
 /* Row-major float64 GEMM on the matrix cores: C = alpha * op(A) op(B) + beta * C, op = transpose when the flag is

@@ -153,6 +153,28 @@ class BasisFunc(nn.Module):
     def forward(self, grid):
         return self.net(grid)
 
+    def fused_forward(self, grid, bf16=False):
+        """Inference through ONE fused HIP kernel (all five 1x1 convolutions chained in MFMA accumulators,
+        csrc/pixel_mlp_kernels.hip) instead of five convolution launches; no autograd graph is recorded."""
+        convs = [m for m in self.net if isinstance(m, nn.Conv2d)]
+        with torch.no_grad():
+            return ops.pixel_mlp_fwd(grid.contiguous(), [c.weight for c in convs], [c.bias for c in convs], bf16=bf16)
+
+
+class PixelMLP(nn.Module):
+    """The configurable-depth generalisation of BasisFunc used by BASELINE configs 2 and 3 (e.g. depth 4 width 32
+    float32; depth 8 width 64 bfloat16): per-pixel Linear-ReLU stack, 3 -> width -> ... -> 3."""
+
+    def __init__(self, depth=4, width=32, c_in=3, c_out=3):
+        super().__init__()
+        dims = [c_in] + [width] * (depth - 1) + [c_out]
+        self.weights = nn.ParameterList([nn.Parameter(torch.randn(dims[i + 1], dims[i]) / dims[i] ** 0.5) for i in range(depth)])
+        self.biases = nn.ParameterList([nn.Parameter(torch.zeros(dims[i + 1])) for i in range(depth)])
+
+    def forward(self, grid, bf16=False):
+        with torch.no_grad():
+            return ops.pixel_mlp_fwd(grid.contiguous(), list(self.weights), list(self.biases), bf16=bf16)
+
 
 class AverageMeter(object):
     """Computes and stores the average and current value (spectral_ode.py:122-137)."""

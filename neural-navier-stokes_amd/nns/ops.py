@@ -300,3 +300,24 @@ def cheb_embed(sol, x0, xN, y0, yN):
     full = torch.empty(Nx, Ny, dtype=torch.float64, device=sol.device)
     check(_lib.lib().nns_cheb_embed_f64(_p(sol), _p(x0), _p(xN), _p(y0), _p(yN), _p(full), Nx, Ny, _stream()), 'nns_cheb_embed_f64')
     return full
+
+
+# ----------------------------------------------------------------------------- per-pixel MLP (BasisFunc)
+def pixel_mlp_fwd(x, weights, biases, bf16=False):
+    """x [mb, C_in, nx, ny] (or [mb, C_in, P]); weights: list of [C_out, C_in] (or Conv2d [C_out, C_in, 1, 1]) tensors;
+    biases: list of [C_out].  ReLU between layers, none after the last."""
+    import ctypes
+    _f32(x)
+    mb, cin = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    ws = [w.reshape(w.shape[0], w.shape[1]) for w in weights]
+    widths = [cin] + [w.shape[0] for w in ws]
+    for i, w in enumerate(ws):
+        if w.shape[1] != widths[i]:
+            raise ValueError("pixel_mlp_fwd: layer %d expects %d input channels, got %d" % (i, w.shape[1], widths[i]))
+    wp = torch.cat([w.reshape(-1) for w in ws]).to(torch.float32).contiguous()
+    bp = torch.cat([b.reshape(-1) for b in biases]).to(torch.float32).contiguous()
+    y = torch.empty((mb, widths[-1]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    arr = (ctypes.c_int * len(widths))(*widths)
+    check(_lib.lib().nns_pixel_mlp_fwd_f32(_p(x), _p(wp), _p(bp), _p(y), mb, P, arr, len(ws), int(bool(bf16)), _stream()), 'nns_pixel_mlp_fwd_f32')
+    return y

@@ -146,3 +146,32 @@ def test_cfg2_size_fused_training_step_vs_oracle(gpu_device):
     before = m.init_coeffs.detach().clone()
     opt.step()
     assert not torch.equal(before, m.init_coeffs.detach())
+
+
+def test_pixel_mlp_basisfunc_vs_golden_and_deep_bf16(gpu_device):
+    """BasisFunc (reference widths 3-16-32-32-16-3) through the fused MFMA kernel vs the reference's output; a
+    depth-8 width-64 stack (config 3) in float32 vs the float64 oracle and in bfloat16 at bf16 tolerance."""
+    from src.neural_spectral.spectral_ode import BasisFunc
+    from nns.neural_spectral.spectral_ode import PixelMLP
+    from nns import ops
+    from oracle import neural as ON
+    bf = BasisFunc(8, 8)
+    bf.load_state_dict({k[len('bf_param_'):]: T(G[k], device='cpu') for k in G.files if k.startswith('bf_param_')})
+    bf = bf.cuda()
+    x = T(G['bf_in'])
+    y = bf.fused_forward(x)
+    assert y.shape == (2, 3, 8, 8)
+    assert rel_l2(y.cpu().numpy(), G['bf_out']) < 1e-5
+    assert rel_l2(bf(x).detach().cpu().numpy(), G['bf_out']) < 1e-5          # the unfused torch path, for reference
+    assert rel_l2(bf.fused_forward(x, bf16=True).cpu().numpy(), G['bf_out']) < 3e-2
+    torch.manual_seed(5)
+    for depth, width, shape in ((8, 64, (3, 3, 37, 41)), (4, 32, (1, 3, 128, 128)), (2, 48, (2, 3, 9, 5)), (1, 3, (1, 3, 4, 4))):
+        m = PixelMLP(depth, width).cuda()
+        for b in m.biases:
+            torch.nn.init.normal_(b, std=0.3)
+        xx = torch.randn(*shape, device='cuda')
+        ref = ON.pixel_mlp([w.detach().cpu().double() for w in m.weights], [b.detach().cpu().double() for b in m.biases], xx.cpu().double()).numpy()
+        assert rel_l2(m(xx).cpu().numpy(), ref) < 1e-5, (depth, width)
+        assert rel_l2(m(xx, bf16=True).cpu().numpy(), ref) < 5e-2, (depth, width)
+    with pytest.raises(Exception):
+        PixelMLP(9, 16).cuda()(torch.randn(1, 3, 4, 4, device='cuda'))           # > 8 layers: unsupported, loud
