@@ -358,44 +358,60 @@ __global__ __launch_bounds__(256) void basis_expand_kernel(const float* __restri
 // compulsory traffic), pred is never written.  MODE 0: sumsq += (pred-obs)^2.  MODE 2: g is READ from `obs`
 // (generic upstream gradient of the materialised prediction).  MODE 1 (backward, g = scale * (pred - obs)): gbasis[k][c][p] = sum_t coeff[t][k][c] g  (registers, written once),
 //                gcoeff[t][k][c] += sum_p basis[k][c][p] g (wave reduction + one atomic per wave).
-template <int MODE>
+// PPT pixels per thread (strided by 256): the cross-lane reduction for gcoeff is paid once per PPT pixels.
+template <int MODE, int PPT, int KMAX>
 __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict__ coeff, const float* __restrict__ basis,
                                                          const float* __restrict__ obs, double* __restrict__ sumsq,
                                                          float* __restrict__ gcoeff, float* __restrict__ gbasis, float scale,
-                                                         int T, int K, int C, int P, int TC) {
+                                                         int T, int K, int C, int P, int TC, int rows_per_split, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* cw = reinterpret_cast<float*>(smem_raw);                  // [TC][K] coefficients of this channel, one chunk of time rows
     const int c = blockIdx.y, tid = threadIdx.x, lane = tid % kWave;
-    const int p = blockIdx.x * 256 + tid;
-    const bool ok = p < P;
-    float fk[kMaxK], gb[kMaxK];
+    const int pbase = blockIdx.x * 256 * PPT + tid;
+    // the time axis is split over blockIdx.z so that a launch has >= ~2048 workgroups even when P*C is small
+    // (ensembles: T = nt*mb is the long axis); partial gbasis sums are then combined with float atomics
+    const int t_lo = blockIdx.z * rows_per_split, t_hi = min(T, t_lo + rows_per_split);
+    float fk[PPT][KMAX], gb[PPT][KMAX];
+    bool ok[PPT];
 #pragma unroll
-    for (int k = 0; k < kMaxK; ++k) { fk[k] = (ok && k < K) ? basis[((size_t)k * C + c) * P + p] : 0.f; gb[k] = 0.f; }
+    for (int i = 0; i < PPT; ++i) {
+        ok[i] = pbase + 256 * i < P;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) { fk[i][k] = (ok[i] && k < K) ? basis[((size_t)k * C + c) * P + pbase + 256 * i] : 0.f; gb[i][k] = 0.f; }
+    }
     double local = 0.0;
-    for (int t0 = 0; t0 < T; t0 += TC) {
-        const int tn = min(TC, T - t0);
+    for (int t0 = t_lo; t0 < t_hi; t0 += TC) {
+        const int tn = min(TC, t_hi - t0);
         __syncthreads();
         for (int e = tid; e < tn * K; e += 256) cw[e] = coeff[((size_t)t0 * K + e) * C + c];
         __syncthreads();
         for (int tt = 0; tt < tn; ++tt) {
             const int t = t0 + tt;
-            float pred = 0.f;
-            if (MODE != 2) {
+            float ob[PPT];
 #pragma unroll
-                for (int k = 0; k < kMaxK; ++k) if (k < K) pred = fmaf(cw[tt * K + k], fk[k], pred);
+            for (int i = 0; i < PPT; ++i) ob[i] = ok[i] ? obs[((size_t)t * C + c) * P + pbase + 256 * i] : 0.f;     // PPT independent loads in flight
+            float g[PPT];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                float pred = 0.f;
+                if (MODE != 2) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) if (k < K) pred = fmaf(cw[tt * K + k], fk[i][k], pred);
+                }
+                const float r = MODE == 2 ? ob[i] : (ok[i] ? pred - ob[i] : 0.f);
+                if (MODE == 0) local += (double)r * (double)r;
+                g[i] = MODE == 2 ? r : scale * r;
             }
-            const float ob = ok ? obs[((size_t)t * C + c) * P + p] : 0.f;
-            const float r = MODE == 2 ? ob : (ok ? pred - ob : 0.f);
-            if (MODE == 0) { local += (double)r * (double)r; }
-            else {
-                const float g = MODE == 2 ? r : scale * r;
+            if (MODE != 0) {
 #pragma unroll
-                for (int k = 0; k < kMaxK; ++k) {
+                for (int k = 0; k < KMAX; ++k) {
                     if (k < K) {
-                        gb[k] = fmaf(cw[tt * K + k], g, gb[k]);
-                        float s = fk[k] * g;
-                        for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_down(s, o);
-                        if (lane == 0) atomicAdd(&gcoeff[((size_t)t * K + k) * C + c], s);
+                        const float w = cw[tt * K + k];
+                        float sred = 0.f;
+#pragma unroll
+                        for (int i = 0; i < PPT; ++i) { gb[i][k] = fmaf(w, g[i], gb[i][k]); sred = fmaf(fk[i][k], g[i], sred); }
+                        for (int o = kWave / 2; o > 0; o >>= 1) sred += __shfl_down(sred, o);
+                        if (lane == 0) atomicAdd(&gcoeff[((size_t)t * K + k) * C + c], sred);
                     }
                 }
             }
@@ -404,10 +420,49 @@ __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict
     if (MODE == 0) {
         for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_down(local, o);
         if (lane == 0) atomicAdd(sumsq, local);
-    } else if (ok) {
+    } else {
 #pragma unroll
-        for (int k = 0; k < kMaxK; ++k) if (k < K) gbasis[((size_t)k * C + c) * P + p] = gb[k];
+        for (int i = 0; i < PPT; ++i) {
+            if (ok[i]) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    if (k < K) {
+                        float* dst = &gbasis[((size_t)k * C + c) * P + pbase + 256 * i];
+                        if (nsplit > 1) atomicAdd(dst, gb[i][k]); else *dst = gb[i][k];
+                    }
+                }
+            }
+        }
     }
+}
+
+struct LossGeom { int TC, rows_per_split, nsplit, ppt; dim3 grid; size_t lds; };
+inline LossGeom loss_geom(int T, int K, int C, int P) {
+    LossGeom g;
+    g.ppt = (K <= 16 && P >= 4096) ? 4 : 1;                               // register budget: 2 * PPT * KMAX floats
+    const int bx = (P + 256 * g.ppt - 1) / (256 * g.ppt);
+    const int bxy = bx * C;
+    int ns = (2048 + bxy - 1) / bxy;
+    const int max_ns = (T + 31) / 32;
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+    g.rows_per_split = (T + ns - 1) / ns;
+    g.nsplit = (T + g.rows_per_split - 1) / g.rows_per_split;
+    const int cap = 8192 / K;                                              // <= 32 KB of coefficients per chunk
+    g.TC = g.rows_per_split < cap ? g.rows_per_split : cap;
+    g.grid = dim3(bx, C, g.nsplit);
+    g.lds = (size_t)g.TC * K * sizeof(float);
+    return g;
+}
+
+template <int MODE>
+void launch_loss(const LossGeom& g, hipStream_t s, const float* coeff, const float* basis, const float* obs, double* sumsq, float* gcoeff,
+                 float* gbasis, float scale, int T, int K, int C, int P) {
+    if (g.ppt == 4)
+        hipLaunchKernelGGL((basis_loss_kernel<MODE, 4, 16>), g.grid, dim3(256), g.lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, g.TC, g.rows_per_split, g.nsplit);
+    else
+        hipLaunchKernelGGL((basis_loss_kernel<MODE, 1, kMaxK>), g.grid, dim3(256), g.lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, g.TC, g.rows_per_split, g.nsplit);
 }
 
 }  // namespace
@@ -478,10 +533,9 @@ NNS_API int nns_basis_expand_f32(const float* coeff, const float* basis, float* 
 NNS_API int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const float* obs, double* sumsq, int T, int K, int C, int P, void* stream) {
     if (!coeff || !basis || !obs || !sumsq || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_fwd: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fwd: K=%d > %d", K, kMaxK);
-    const int TC = T < (8192 / K) ? T : (8192 / K);                     // time rows per LDS coefficient chunk (<= 32 KB)
-    const size_t lds = (size_t)TC * K * sizeof(float);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fwd: C must be <= 65535");
-    hipLaunchKernelGGL(basis_loss_kernel<0>, dim3((P + 255) / 256, C), dim3(256), lds, S(stream), coeff, basis, obs, sumsq, nullptr, nullptr, 0.f, T, K, C, P, TC);
+    const LossGeom g = loss_geom(T, K, C, P);
+    launch_loss<0>(g, S(stream), coeff, basis, obs, sumsq, nullptr, nullptr, 0.f, T, K, C, P);
     return check_launch("basis_loss_fwd");
 }
 
@@ -490,12 +544,12 @@ NNS_API int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const
                                    int T, int K, int C, int P, void* stream) {
     if (!coeff || !basis || !obs || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_bwd: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: K=%d > %d", K, kMaxK);
-    const int TC = T < (8192 / K) ? T : (8192 / K);                     // time rows per LDS coefficient chunk (<= 32 KB)
-    const size_t lds = (size_t)TC * K * sizeof(float);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: C must be <= 65535");
+    const LossGeom g = loss_geom(T, K, C, P);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
+    if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_bwd: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(basis_loss_kernel<1>, dim3((P + 255) / 256, C), dim3(256), lds, S(stream), coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P, TC);
+    launch_loss<1>(g, S(stream), coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P);
     return check_launch("basis_loss_bwd");
 }
 
@@ -504,11 +558,11 @@ NNS_API int nns_basis_expand_bwd_f32(const float* coeff, const float* basis, con
                                      int T, int K, int C, int P, void* stream) {
     if (!coeff || !basis || !grad_pred || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_expand_bwd: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: K=%d > %d", K, kMaxK);
-    const int TC = T < (8192 / K) ? T : (8192 / K);
-    const size_t lds = (size_t)TC * K * sizeof(float);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: C must be <= 65535");
+    const LossGeom g = loss_geom(T, K, C, P);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
+    if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_expand_bwd: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(basis_loss_kernel<2>, dim3((P + 255) / 256, C), dim3(256), lds, S(stream), coeff, basis, grad_pred, nullptr, gcoeff, gbasis, 1.f, T, K, C, P, TC);
+    launch_loss<2>(g, S(stream), coeff, basis, grad_pred, nullptr, gcoeff, gbasis, 1.f, T, K, C, P);
     return check_launch("basis_expand_bwd");
 }
