@@ -142,14 +142,18 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
         C2<T> y[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) y[t] = x[q + NB * t];
+#ifndef NNS_TW_LOOKUP
+#define NNS_TW_LOOKUP 0      // 0: float64 twiddles by running product from one table read; 1: grouped table reads
+#endif
         if constexpr (NS == 16) {
             // second pass: twiddle W_N^{t * c * N/(16 R)}, c = j mod 16, from the pass-2 table laid out [t][c]:
             // for a given t the lanes of a wave read 16 CONSECUTIVE entries (conflict-free, broadcast across
             // the lane groups that share c); striding the main table by t*c*N/(16R) was up to 16-way conflicted.
-            const int c = j & 15;
-            if constexpr (sizeof(T) == 8) {
-                // float64: ONE table read, the other R-2 twiddles by running product (14 roundings of
-                // 1e-16 are irrelevant here, and 15 hoisted double2 reads would cost 60 VGPRs)
+            int c = j & 15;
+            if constexpr (sizeof(T) == 8 && !NNS_TW_LOOKUP) {
+                // float64: ONE table read, the other R-2 twiddles by running product (14 roundings of 1e-16 are
+                // irrelevant, and 15 hoisted double2 reads would cost 60 VGPRs).  Grouped table reads (pinned
+                // three at a time) save 56 fp64 ops per pass but measured slower on MI355X (A/B on one box).
                 C2<T> w = tab2[16 + c];
                 if constexpr (INV) w.y = -w.y;
                 C2<T> wt = w;
@@ -159,14 +163,17 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
             } else {
 #pragma unroll
                 for (int t = 1; t < R; ++t) {
+                    // table reads pinned in groups (3 for float64, 4 for float32) so they are not all hoisted
+                    if constexpr (sizeof(T) == 8) { if (t % 3 == 1) asm volatile("" : "+v"(c), "+v"(y[t].x)); }
+                    else { if (t % 4 == 1) asm volatile("" : "+v"(c), "+v"(y[t].x)); }
                     C2<T> w = tab2[16 * t + c];
                     if constexpr (INV) w.y = -w.y;
                     y[t] = cmul<T>(y[t], w);
                 }
             }
         } else if constexpr (NS > 1) {
-            const int jm = (j & (NS - 1)) * (N / (NS * R));
-            if constexpr (sizeof(T) == 8) {
+            int jm = (j & (NS - 1)) * (N / (NS * R));
+            if constexpr (sizeof(T) == 8 && !NNS_TW_LOOKUP) {
                 const C2<T> w = twiddle<T, N, INV>(tab, jm);
                 C2<T> wt = w;
                 y[1] = cmul<T>(y[1], wt);
@@ -174,7 +181,10 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
                 for (int t = 2; t < R; ++t) { wt = cmul<T>(wt, w); y[t] = cmul<T>(y[t], wt); }
             } else {
 #pragma unroll
-                for (int t = 1; t < R; ++t) y[t] = cmul<T>(y[t], twiddle<T, N, INV>(tab, t * jm));
+                for (int t = 1; t < R; ++t) {
+                    if constexpr (sizeof(T) == 8) { if (t % 3 == 1) asm volatile("" : "+v"(jm), "+v"(y[t].x)); }
+                    y[t] = cmul<T>(y[t], twiddle<T, N, INV>(tab, t * jm));
+                }
             }
         }
         dftR<T, R, INV>(y);

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libnns_hip.so')
+# NNS_LIB_PATH: developer override used for same-box A/B timing of kernel variants (default: the in-tree build)
+LIB_PATH = os.environ.get('NNS_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libnns_hip.so')
 NNS_MAX_BC = 8
 
 
