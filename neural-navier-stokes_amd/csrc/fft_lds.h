@@ -142,6 +142,9 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
         C2<T> y[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) y[t] = x[q + NB * t];
+#ifndef NNS_F32_PIN
+#define NNS_F32_PIN 1      // pin float32 pass-2 table reads in groups of 4 (limits hoisting)
+#endif
 #ifndef NNS_TW_LOOKUP
 #define NNS_TW_LOOKUP 0      // 0: float64 twiddles by running product from one table read; 1: grouped table reads
 #endif
@@ -165,7 +168,7 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
                 for (int t = 1; t < R; ++t) {
                     // table reads pinned in groups (3 for float64, 4 for float32) so they are not all hoisted
                     if constexpr (sizeof(T) == 8) { if (t % 3 == 1) asm volatile("" : "+v"(c), "+v"(y[t].x)); }
-                    else { if (t % 4 == 1) asm volatile("" : "+v"(c), "+v"(y[t].x)); }
+                    else if (NNS_F32_PIN) { if (t % 4 == 1) asm volatile("" : "+v"(c), "+v"(y[t].x)); }
                     C2<T> w = tab2[16 * t + c];
                     if constexpr (INV) w.y = -w.y;
                     y[t] = cmul<T>(y[t], w);

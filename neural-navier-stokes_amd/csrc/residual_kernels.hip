@@ -23,8 +23,8 @@ using namespace nns;
 namespace {
 
 template <typename T> struct VecT;
-template <> struct VecT<float> { using type = float4; static constexpr int V = 4; };
-template <> struct VecT<double> { using type = double2; static constexpr int V = 2; };
+template <> struct VecT<float> { using type = float4; using native = __attribute__((ext_vector_type(4))) float; static constexpr int V = 4; };
+template <> struct VecT<double> { using type = double2; using native = __attribute__((ext_vector_type(2))) double; static constexpr int V = 2; };
 
 // Second differences (and the 9-point cross term) cancel O(1) values down to O(h^2): in float32 the
 // rounding of those sums, multiplied by 1/h^2 ~ 3e4 at 1024^2, is what limits the residual to ~2e-5
@@ -45,9 +45,22 @@ inline ResK<T> make_resk(double dt, double dx, double dy, double rho, double nu)
 template <typename T, int V>
 struct Row { T v[V]; T l, r; };          // V consecutive columns of one row + the two neighbours
 
+#ifndef NNS_FD_NT
+#define NNS_FD_NT 0        // 1: non-temporal hint on the write-once outputs and read-once u_prev / v_prev streams
+#endif
+#ifndef NNS_FD_RMAX
+#define NNS_FD_RMAX 32     // tallest band a workgroup marches down
+#endif
 template <typename T>
-__device__ __forceinline__ void load_vec(const T* p, T (&out)[VecT<T>::V]) {
+__device__ __forceinline__ void load_vec(const T* p, T (&out)[VecT<T>::V], bool nt = false) {
     using VT = typename VecT<T>::type;
+    if (NNS_FD_NT && nt) {
+        using NV = typename VecT<T>::native;
+        const NV n = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+#pragma unroll
+        for (int e = 0; e < VecT<T>::V; ++e) out[e] = n[e];
+        return;
+    }
     const VT t = *reinterpret_cast<const VT*>(p);
     if constexpr (VecT<T>::V == 4) { out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
     else { out[0] = t.x; out[1] = t.y; }
@@ -59,7 +72,13 @@ __device__ __forceinline__ void store_vec(T* p, const T (&in)[VecT<T>::V]) {
     VT t;
     if constexpr (VecT<T>::V == 4) { t.x = in[0]; t.y = in[1]; t.z = in[2]; t.w = in[3]; }
     else { t.x = in[0]; t.y = in[1]; }
-    *reinterpret_cast<VT*>(p) = t;
+    if (NNS_FD_NT) {
+        using NV = typename VecT<T>::native;
+        NV n;
+#pragma unroll
+        for (int e = 0; e < VecT<T>::V; ++e) n[e] = in[e];
+        __builtin_nontemporal_store(n, reinterpret_cast<NV*>(p));
+    } else *reinterpret_cast<VT*>(p) = t;
 }
 
 // One row of one field: the lane's vector, plus left/right neighbours taken from the adjacent
@@ -112,8 +131,8 @@ __global__ __launch_bounds__(256) void fd_residual_vec_kernel(const T* __restric
         load_row<T>(vg + rn, j0, jl, jr, need_l, need_r, vn);
         load_row<T>(pg + rn, j0, jl, jr, need_l, need_r, pn);
         T upv[V], vpv[V], o_u[V], o_v[V], o_d[V];
-        load_vec<T>(up + rc, upv);
-        load_vec<T>(vp + rc, vpv);
+        load_vec<T>(up + rc, upv, true);
+        load_vec<T>(vp + rc, vpv, true);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const T ucc = uc.v[e], vcc = vc.v[e];
@@ -189,7 +208,7 @@ int fd_residual(const T* u, const T* v, const T* p, const T* up, const T* vp, T*
         // rows per band: aim for >= 2048 workgroups, keep the halo overhead (R+2)/R small
         long want = 2048;
         int R = (int)(((long)batch * nx * nstrips + want - 1) / want);
-        R = R < 4 ? 4 : (R > 32 ? 32 : R);
+        R = R < 4 ? 4 : (R > NNS_FD_RMAX ? NNS_FD_RMAX : R);
         const int nbands = (nx + R - 1) / R;
         const long nblocks = (long)batch * nbands * nstrips;
         if (nblocks > 0x7fffffffL) return fail(NNS_ERR_UNSUPPORTED, "fd_residual: grid too large");
