@@ -165,6 +165,14 @@ int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, 
                                 const float* v_prev, float* r_u, float* r_v, float* r_div,
                                 int batch, int nx, int ny, double dt, double Ly,
                                 double rho, double nu, int precise, void* stream);
+/* Spectral derivatives of ONE real field (d/dx <-> i kx with the Nyquist mode dropped, lap <-> -|k|^2; definition
+ * oracle/periodic.py: spectral_derivs): any of f_x, f_y, f_lap may be NULL.  precise as above. */
+int nns_spec_derivs_f32(const float* f, float* f_x, float* f_y, float* f_lap, int batch, int nx, int ny,
+                        double Lx, double Ly, int precise, void* stream);
+/* 2-D real FFT pair with numpy.fft.rfft2 / irfft2 layout and normalisation (float32 transforms): spec is interleaved
+ * complex64 [batch, nx, ny/2+1].  irfft2 uses spec as scratch for its column pass (spec is overwritten). */
+int nns_spec_rfft2_f32(const float* f, float* spec, int batch, int nx, int ny, void* stream);
+int nns_spec_irfft2_f32(float* spec, float* f, int batch, int nx, int ny, void* stream);
 
 /* ---- neural_spectral field predictor: src/neural_spectral/spectral_ode.py, anode/ ------------ */
 enum { NNS_ODE_EULER = 0, NNS_ODE_RK2 = 1, NNS_ODE_RK4 = 2 };   /* anode/scheme.py:21-42 */

@@ -45,6 +45,9 @@ _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_xpass_f32': [_P] * 6 + [_I] * 3 + [_D] * 3 + [_I, _P],
     'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_spec_derivs_f32': [_P] * 4 + [_I] * 3 + [_D, _D, _I, _P],
+    'nns_spec_rfft2_f32': [_P, _P, _I, _I, _I, _P],
+    'nns_spec_irfft2_f32': [_P, _P, _I, _I, _I, _P],
     'nns_pixel_mlp_fwd_f32': [_P] * 4 + [_I, _I, C.POINTER(C.c_int), _I, _I, _P],
     'nns_cheb_gemm_f64': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _D, _D, _I, _P],
     'nns_cheb_helmholtz_rhs_f64': [_P] * 12 + [_I, _D, _P],

@@ -321,3 +321,34 @@ def pixel_mlp_fwd(x, weights, biases, bf16=False):
     arr = (ctypes.c_int * len(widths))(*widths)
     check(_lib.lib().nns_pixel_mlp_fwd_f32(_p(x), _p(wp), _p(bp), _p(y), mb, P, arr, len(ws), int(bool(bf16)), _stream()), 'nns_pixel_mlp_fwd_f32')
     return y
+
+
+# ----------------------------------------------------------------------------- standalone spectral operators
+def spec_derivs(f, Lx, Ly, want=('x', 'y', 'lap'), precise=True):
+    """Spectral f_x, f_y, lap f of one real float32 field [B, nx, ny] (or [nx, ny]); returns a dict."""
+    _f32(f)
+    B, nx, ny = _dims(f)
+    out = {k: torch.empty_like(f) for k in want}
+    ptr = lambda k: _p(out[k]) if k in out else None
+    check(_lib.lib().nns_spec_derivs_f32(_p(f), ptr('x'), ptr('y'), ptr('lap'), B, nx, ny, float(Lx), float(Ly), int(bool(precise)), _stream()),
+          'nns_spec_derivs_f32')
+    return out
+
+
+def spec_rfft2(f):
+    """numpy.fft.rfft2 of float32 [B, nx, ny] -> complex64 [B, nx, ny//2+1]."""
+    _f32(f)
+    B, nx, ny = _dims(f)
+    spec = torch.empty((B, nx, ny // 2 + 1, 2), dtype=torch.float32, device=f.device)
+    check(_lib.lib().nns_spec_rfft2_f32(_p(f), _p(spec), B, nx, ny, _stream()), 'nns_spec_rfft2_f32')
+    return torch.view_as_complex(spec)
+
+
+def spec_irfft2(spec, ny):
+    """numpy.fft.irfft2(spec, s=(nx, ny)) for complex64 [B, nx, ny//2+1]; the input is not modified (a scratch copy is)."""
+    s = torch.view_as_real(spec.contiguous()).clone()
+    _f32(s)
+    B, nx = spec.shape[0], spec.shape[1]
+    f = torch.empty((B, nx, ny), dtype=torch.float32, device=spec.device)
+    check(_lib.lib().nns_spec_irfft2_f32(_p(s), _p(f), B, nx, ny, _stream()), 'nns_spec_irfft2_f32')
+    return f

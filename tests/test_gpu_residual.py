@@ -184,3 +184,31 @@ def test_slab_residual_single_rank_uses_hip_backend(gpu_device):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 128), (1, 256, 64), (1, 1024, 1024)])
+def test_rfft2_irfft2_match_numpy(shape, gpu_device):
+    from nns import ops
+    rng = np.random.default_rng(12)
+    f = rng.standard_normal(shape).astype(np.float32)
+    spec = ops.spec_rfft2(dev(f))
+    ref = np.fft.rfft2(f.astype(np.float64))
+    assert spec.shape == ref.shape and spec.dtype == torch.complex64
+    crel = lambda a, b: np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())          # complex-aware
+    assert crel(spec.cpu().numpy().astype(np.complex128), ref) < 2e-6
+    back = ops.spec_irfft2(spec, shape[2])
+    assert rel_l2(back.cpu().numpy(), f) < 2e-6
+    back2 = ops.spec_irfft2(torch.as_tensor(ref.astype(np.complex64), device='cuda'), shape[2])   # from numpy's spectrum
+    assert rel_l2(back2.cpu().numpy(), np.fft.irfft2(ref, s=shape[1:])) < 2e-6
+
+
+@pytest.mark.parametrize('n', [64, 256, 1024])
+def test_spec_derivs_vs_oracle(n, gpu_device):
+    from nns import ops
+    from oracle import periodic as OP
+    f = inputs(2, n)[0]
+    d = ops.spec_derivs(dev(f), L, 2 * L)
+    fx, fy, lap = OP.spectral_derivs(f.astype(np.float64), L, 2 * L)
+    assert rel_l2(d['x'].cpu().numpy(), fx) < TOL and rel_l2(d['y'].cpu().numpy(), fy) < TOL and rel_l2(d['lap'].cpu().numpy(), lap) < TOL
+    only = ops.spec_derivs(dev(f), L, 2 * L, want=('y',))
+    assert list(only) == ['y'] and torch.equal(only['y'], d['y'])
