@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--stencil', type=int, default=5)
     ap.add_argument('--fast', action='store_true', help='all-float32 spectral path (2e-4 rel-L2) instead of the precise one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse the multi-process path on a one-GPU box)")
     ap.add_argument('--mode', choices=['batch', 'slab'], default='batch',
                     help="batch: every rank owns --batch whole grids, no collective (weak scaling, default); "
                          "slab: the SAME --batch grids are slab-decomposed by rows over the ranks -- RCCL halo "
@@ -114,13 +116,18 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
                              "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py ..." % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == 'nccl' else local_rank % max(ndev, 1)     # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)          # "nccl" is RCCL on ROCm
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group('gloo')
 
     from nns import ops, _lib
     from nns.periodic import ResidualEngine
@@ -164,7 +171,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -38,11 +38,14 @@ def cfg1():
     for method in ('explicit', 'semi_implicit'):
         for B in (1, 256):
             z = np.zeros((n, n)) if B == 1 else np.zeros((B, n, n))
-            s = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=20, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02,
+            nt = 200                                                   # the reference driver's nt (:278)
+            s = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=nt, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02,
                                    beta=1.25, method=method)
-            dt = timeit(lambda: s.simulate_device(), iters=3, warm=1) / 20
-            out['%s_B%d_ms_per_step' % (method, B)] = 1e3 * dt
-            out['%s_B%d_pt_steps_per_s' % (method, B)] = B * n * n / dt
+            for graph in (True, False):
+                dt = timeit(lambda: s.simulate_device(use_graph=graph), iters=2, warm=1) / nt
+                tag = '%s_B%d_%s' % (method, B, 'graph' if graph else 'eager')
+                out[tag + '_ms_per_step'] = 1e3 * dt
+                out[tag + '_pt_steps_per_s'] = B * n * n / dt
     return dict(config='cfg1 chorin_fd 64x64 cavity Re=100, nit=50, float64 (reference CPU: 0.51 s/step)', **out)
 
 

@@ -370,8 +370,12 @@ int jacobi(T* p, T* tmp, const T* b, int batch, int nx, int ny, double dx, doubl
     JacK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx + dy * dy)), (T)((dx * dx) * (dy * dy) / (2 * (dx * dx + dy * dy)))};
     const size_t lds = 3 * (size_t)nx * ny * sizeof(T);
     if (lds <= 150 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_jacobi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_jacobi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
         hipLaunchKernelGGL(jacobi_lds_kernel<T>, dim3(batch), dim3(1024), lds, s, p, b, nx, ny, nit, k, d);
         return check_launch("fd_jacobi(lds)");
     }

@@ -121,8 +121,12 @@ int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double
     const size_t lds = kSorHdr + 2 * (size_t)nx * ny * sizeof(T);
     T* snap = reinterpret_cast<T*>(work);
     if (lds <= 150 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        static bool attr = false;                     // set once to the largest size used (keeps the launch path free of
+        if (!attr) {                                  // non-stream API calls, e.g. under hipGraph capture)
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
         hipLaunchKernelGGL((sor_kernel<T, true>), dim3(batch), dim3(kSorThreads), lds, s, p, C, info, snap, nx, ny, max_sweeps, k);
     } else {
         hipLaunchKernelGGL((sor_kernel<T, false>), dim3(batch), dim3(kSorThreads), kSorHdr, s, p, C, info, snap, nx, ny, max_sweeps, k);

@@ -117,13 +117,28 @@ class NavierStokesSystem():
         ops.bc_apply_(p, self._p_bcl)
         return u, v, p
 
-    def simulate_device(self):
+    def simulate_device(self, use_graph=None):
         """The time loop with everything resident on the GPU; returns device tensors
-        [nt, (B,) nx, ny] in the working dtype (no host transfer)."""
+        [nt, (B,) nx, ny] in the working dtype (no host transfer).  ``use_graph=True`` captures one step in a hipGraph
+        (static state buffers) and replays it; results are bitwise identical.  It is OFF by default: measured on
+        MI355X at 64^2, nit = 50 the step is bound by the SOR kernel (~600 barrier-separated pipeline steps, 0.25 ms),
+        not by launch overhead -- replay 0.287 ms/step vs eager 0.270 ms/step."""
         u, v, p = self._init_variables()
         u1, v1 = u.clone(), v.clone()
         us = torch.empty((self.nt,) + tuple(u.shape), dtype=u.dtype, device=u.device)
         vs, ps = torch.empty_like(us), torch.empty_like(us)
+        if use_graph:
+            self._step_dev(u.clone(), v.clone(), u1.clone(), v1.clone(), p.clone())        # warm-up outside capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                _u, _v, _ = self._step_dev(u, v, u1, v1, p)                               # p is updated in place
+                u1.copy_(u), v1.copy_(v)
+                u.copy_(_u), v.copy_(_v)
+            for n in range(self.nt):
+                g.replay()
+                us[n].copy_(u), vs[n].copy_(v), ps[n].copy_(p)
+            return us, vs, ps
         for n in range(self.nt):
             _u, _v, p = self._step_dev(u, v, u1, v1, p)
             u1, v1 = u, v

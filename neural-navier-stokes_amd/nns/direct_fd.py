@@ -76,12 +76,22 @@ class NavierStokesSystem():
                 host[...] = dev.cpu().numpy()
         return u, v, p
 
-    def simulate_device(self):
+    def simulate_device(self, use_graph=False):
         u, v, p = self._d(self.u_ic), self._d(self.v_ic), self._d(self.p_ic)
         if isinstance(self.u_ic, torch.Tensor):
             u, v, p = u.clone(), v.clone(), p.clone()
         us = torch.empty((self.nt,) + tuple(u.shape), dtype=u.dtype, device=u.device)
         vs, ps = torch.empty_like(us), torch.empty_like(us)
+        if use_graph:                                      # capture one step in a hipGraph and replay it (see chorin_fd)
+            self._step_dev_(u.clone(), v.clone(), p.clone())
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_dev_(u, v, p)
+            for n in range(self.nt):
+                g.replay()
+                us[n].copy_(u), vs[n].copy_(v), ps[n].copy_(p)
+            return us, vs, ps, (u, v, p)
         for n in range(self.nt):
             self._step_dev_(u, v, p)
             us[n].copy_(u), vs[n].copy_(v), ps[n].copy_(p)

@@ -302,3 +302,24 @@ def test_direct_fd_cavity_trajectory(n, gpu_device):
         ul, vl, pl = s.simulate()
         assert rel_l2(ul[sel], g['u']) <= tol and rel_l2(vl[sel], g['v']) <= tol and rel_l2(pl[sel], g['p']) <= tol
         assert np.abs(u_ic).max() > 0                        # the reference's simulate mutates the caller's ICs (:132)
+
+
+def test_graph_replay_equals_eager_loop(gpu_device):
+    """simulate_device(use_graph=True) captures one step in a hipGraph: results must be bitwise those of the eager loop."""
+    from nns.chorin_fd import NavierStokesSystem
+    from nns.direct_fd import NavierStokesSystem as DirectNS
+    from oracle.boundary import cavity_bcs
+    n = 32
+    dx = dy = 2. / (n - 1)
+    u_bc, v_bc, p_bc = cavity_bcs(dx, dy)
+    z = np.zeros((n, n))
+    for method in ('explicit', 'semi_implicit'):
+        s = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=12, nit=30, nx=n, ny=n, dt=1e-3, rho=1, nu=0.05, beta=1.25, method=method)
+        a = s.simulate_device(use_graph=True)
+        b = s.simulate_device(use_graph=False)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    d = DirectNS(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=12, nit=20, nx=n, ny=n, dt=1e-3, rho=1, nu=0.1)
+    ug = d.simulate_device(use_graph=True)[0]
+    d2 = DirectNS(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=12, nit=20, nx=n, ny=n, dt=1e-3, rho=1, nu=0.1)
+    assert torch.equal(ug, d2.simulate_device(use_graph=False)[0])
