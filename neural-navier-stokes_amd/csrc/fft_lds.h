@@ -21,6 +21,7 @@
 // LDS, one table per arithmetic type in use.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace nns {
 
@@ -211,18 +212,29 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
 }
 
 // Full transform (unnormalised).  In and out: x[m] = element tid + TPF*m, natural order.
-template <typename T, int N, bool INV>
+// `hook(std::integral_constant<int, SLOT0 + i>{})` is called after pass i: callers use these points to trickle
+// global-memory instructions into the arithmetic (see spec_xpass_kernel).  FftPasses<N>::value passes per line.
+template <int N> struct FftPasses { static constexpr int value = (N / 16 <= 16) ? 2 : 3; };
+struct NoHook { template <typename S> __device__ __forceinline__ void operator()(S) const {} };
+
+template <typename T, int N, bool INV, int SLOT0 = 0, typename Hook = NoHook>
 __device__ __forceinline__ void fft_line(C2<T> (&x)[16], const C2<T>* __restrict__ tab, const C2<T>* __restrict__ tab2,
-                                         C2<T>* __restrict__ xb, int tid) {
+                                         C2<T>* __restrict__ xb, int tid, Hook&& hook = Hook{}) {
     static_assert(N == 64 || N == 128 || N == 256 || N == 512 || N == 1024, "supported line lengths");
     fft_pass<T, N, 16, 1, INV>(x, tab, tab2, xb, tid);
+    hook(std::integral_constant<int, SLOT0>{});
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (N / 16 < 16) {
         fft_pass<T, N, N / 16, 16, INV>(x, tab, tab2, xb, tid);
+        hook(std::integral_constant<int, SLOT0 + 1>{});
     } else {
         fft_pass<T, N, 16, 16, INV>(x, tab, tab2, xb, tid);
+        hook(std::integral_constant<int, SLOT0 + 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (N / 256 > 1) fft_pass<T, N, N / 256, 256, INV>(x, tab, tab2, xb, tid);
+        if constexpr (N / 256 > 1) {
+            fft_pass<T, N, N / 256, 256, INV>(x, tab, tab2, xb, tid);
+            hook(std::integral_constant<int, SLOT0 + 2>{});
+        }
     }
 }
 

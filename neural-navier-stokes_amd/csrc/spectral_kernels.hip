@@ -71,11 +71,13 @@ __device__ __forceinline__ void wavenumber(int e, int& k_odd, int& k_even) {
 // The shared core: from the line's u, v, p (element tid + TPF*m in slot m) produce
 //   a = (f_u', f_v')  and  b = (L_u, L_v)  with the pressure-gradient term added to the real part
 //   (P_IN_REAL, x-pass) or the imaginary part (y-pass) of b.
-template <int N, typename TF, bool P_IN_REAL>
+// `hook` is called at the 4 * FftPasses<N> pass boundaries (slot numbers 0 .. 4 P - 1), see fft_line.
+template <int N, typename TF, bool P_IN_REAL, typename Hook = NoHook>
 __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&vf)[16], const float (&pf)[16],
                                            C2<float> (&a)[16], C2<float> (&b)[16],
                                            const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid,
-                                           const SpecK& k) {
+                                           const SpecK& k, Hook&& hook = Hook{}) {
+    constexpr int P = FftPasses<N>::value;
     constexpr int TPF = N / 16;
     const C2<TF>* tabF2 = tabF + N / 2;
     const C2<float>* tabI2 = tabI + N / 2;
@@ -85,7 +87,7 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     // ---- pressure: Z2 = FFT(p); keep only its contribution to b, already scaled, in float
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
-    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    fft_line<TF, N, false, 0>(z, tabF, tabF2, xbF, tid, hook);
     // The per-element wavenumber factors depend only on the lane id: left alone, instruction selection
     // computes all 16 (fp64) during the butterflies above and spills them.  Tie the lane id to the
     // transform's output so they are computed here, where they are used.
@@ -103,7 +105,7 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     // ---- velocity: Z1 = FFT(u + i v)
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)uf[m]; z[m].y = (TF)vf[m]; }
-    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    fft_line<TF, N, false, P>(z, tabF, tabF2, xbF, tid, hook);
     te = tid;
     asm volatile("" : "+v"(te), "+v"(z[0].x));
 #pragma unroll
@@ -118,9 +120,9 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     }
     // ---- inverse transforms in float32
     __builtin_amdgcn_sched_barrier(0);
-    fft_line<float, N, true>(a, tabI, tabI2, xbI, tid);
+    fft_line<float, N, true, 2 * P>(a, tabI, tabI2, xbI, tid, hook);
     __builtin_amdgcn_sched_barrier(0);
-    fft_line<float, N, true>(b, tabI, tabI2, xbI, tid);
+    fft_line<float, N, true, 3 * P>(b, tabI, tabI2, xbI, tid, hook);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -276,9 +278,34 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (PREFETCH && t + gridDim.x < ntiles) issue_loads(t + gridDim.x);  // prefetch the next tile (in flight during the FFTs)
+        // Prefetch of the next tile, TRICKLED: a burst of 48 loads per thread (each wave-instruction touching 8
+        // separate 32-byte row pieces) keeps every wave of every CU in vector-memory issue at the same time --
+        // measured 0.17 ms of a 0.79 ms kernel at 1024^2 x 64.  Instead a few row pieces are requested at each of
+        // the 4 P FFT-pass boundaries, where other waves' arithmetic covers the issue time.
+        const long tn = t + gridDim.x < ntiles ? t + gridDim.x : t;          // clamped: the last prefetch re-reads this tile
+        int j0n; size_t gn;
+        tile_coords(tn, j0n, gn);
+        auto load_chunk = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            int ty = threadIdx.x;
+            asm volatile("" : "+v"(ty));
+            const int cc = ty % CW, cr = ty / CW;
+            const int col = j0n + cc < ny ? j0n + cc : ny - 1;                // clamped column: no mask needed on a load
+            const size_t c = gn + (size_t)(cr + ROWS_PER_IT * i) * ny + col;
+            su[i] = u[c]; sv[i] = v[c]; sp[i] = p[c];
+        };
+        auto hook = [&](auto sc) {
+            if constexpr (PREFETCH) {
+                constexpr int NSLOT = 4 * FftPasses<N>::value;
+                constexpr int s = decltype(sc)::value;
+                constexpr int c0 = NR * s / NSLOT, c1 = NR * (s + 1) / NSLOT;
+                static_assert(c1 - c0 <= 2, "at most two chunks per slot");
+                if constexpr (c1 > c0) load_chunk(std::integral_constant<int, c0>{});
+                if constexpr (c1 > c0 + 1) load_chunk(std::integral_constant<int, c0 + 1>{});
+            }
+        };
         C2<float> a[16], b2[16];
-        deriv_core<N, TF, true>(uf, vf, pf, a, b2, tabF, tabI, xb, tidv, k);
+        deriv_core<N, TF, true>(uf, vf, pf, a, b2, tabF, tabI, xb, tidv, k, hook);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
