@@ -29,6 +29,7 @@
 #include "nns_common.h"
 #include "fft_lds.h"
 #include <type_traits>
+#include <cstdlib>
 
 using namespace nns;
 
@@ -335,6 +336,13 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
     }
 }
 
+// workgroups per launch (grid-stride over tiles): 2 generations per CU -- each generation pays the twiddle-table
+// setup and one exposed first-tile load (2048 cost the x-pass 6 %, same-box sweep); NNS_SPEC_GRID overrides it for tuning
+inline long spec_grid_cap() {
+    static const long cap = [] { const char* e = getenv("NNS_SPEC_GRID"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
+    return cap;
+}
+
 template <int N, typename TF>
 int launch_xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int ny, const SpecK& k, hipStream_t s) {
     using L = SpecLds<N, TF>;
@@ -349,7 +357,8 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec xpass: hipFuncSetAttribute(%d B): %s", L::TOTAL, hipGetErrorString(e));
         attr_set = true;
     }
-    const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);
+    const long gmax = spec_grid_cap();
+    const unsigned grid = (unsigned)(ntiles < gmax ? ntiles : gmax);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, ru, rv, rd, ny, tiles_per_grid, ntiles, k);
     return check_launch("spec_residual_xpass");
 }
@@ -366,7 +375,8 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
         attr_set = true;
     }
     const long niter = (nrows + L::LINES - 1) / L::LINES;
-    const unsigned grid = (unsigned)(niter < 2048 ? niter : 2048);
+    const long gmax = spec_grid_cap();
+    const unsigned grid = (unsigned)(niter < gmax ? niter : gmax);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, nrows, k);
     return check_launch("spec_residual_ypass");
 }
