@@ -160,44 +160,70 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
     C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
     spec_setup<N, TF>(smem, tabF, tabI, lines);
     const long niter = (nrows + L::LINES - 1) / L::LINES;
-    for (long it = blockIdx.x; it < niter; it += gridDim.x) {
+    // element offset of this lane's first element of the line it owns in iteration `it` (row clamped into range)
+    auto line_base = [&](long it) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const long row_raw = it * L::LINES + wave * L::FPW + lane / TPF;
+        return (size_t)(row_raw < nrows ? row_raw : nrows - 1) * N + lane % TPF;
+    };
+    // Software pipeline: the NEXT line's u, v, p are requested when the inverse transforms start (registers are
+    // slack there: the float64 spectra are dead) and are consumed at the top of the next iteration.
+    float nu[16], nv[16], np[16];
+    long it = blockIdx.x;
+    if (it >= niter) return;
+    {
+        const size_t b0 = line_base(it);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { nu[m] = u[b0 + TPF * m]; nv[m] = v[b0 + TPF * m]; np[m] = p[b0 + TPF * m]; }
+    }
+    for (; it < niter; it += gridDim.x) {
         int tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
         const int wave = tx / kWave, lane = tx % kWave;
         const int sub = lane / TPF, tid = lane % TPF;
         const int line = wave * L::FPW + sub;
         unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
-        const long row_raw = it * L::LINES + line;
-        const bool valid = row_raw < nrows;
-        const long row = valid ? row_raw : nrows - 1;
+        const bool valid = it * L::LINES + line < nrows;
         // Per-lane loop invariants (wavenumber factors, twiddle reads) would be hoisted out of this loop
         // by LICM and pinned in ~150 VGPRs for the whole body: make the lane id opaque per iteration.
         int tidv = tid;
         asm volatile("" : "+v"(tidv));
-        const size_t base = (size_t)row * N + tidv;
-        // Memory phases are batched so that a line costs TWO exposed HBM round trips (prologue, epilogue), each
-        // with all of its loads in flight, instead of one per element: the r_* arrays are read and written
-        // through the same pointers, so an interleaved load/compute/store loop is serialised by the compiler.
-        float uf[16], vf[16], pf[16], du[16], dv[16];
+        const size_t base = line_base(it);
+        // Memory phases are batched (all loads of a phase in flight together); the r_* arrays are read and written
+        // through the same pointers, so an interleaved load/compute/store loop would be serialised by the compiler.
+        float uf[16], vf[16], pf[16];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            uf[m] = u[base + TPF * m]; vf[m] = v[base + TPF * m]; pf[m] = p[base + TPF * m];
-            du[m] = up[base + TPF * m]; dv[m] = vp[base + TPF * m];
-        }
+        for (int m = 0; m < 16; ++m) { uf[m] = nu[m]; vf[m] = nv[m]; pf[m] = np[m]; }
+        const size_t nbase = line_base(it + gridDim.x < niter ? it + gridDim.x : it);
+        auto hook = [&](auto sc) {
+            if constexpr (decltype(sc)::value == 2 * FftPasses<N>::value - 1) {          // after the last forward pass
 #pragma unroll
-        for (int m = 0; m < 16; ++m) { du[m] = (uf[m] - du[m]) * k.inv_dt; dv[m] = (vf[m] - dv[m]) * k.inv_dt; }
+                for (int m = 0; m < 16; ++m) { nu[m] = u[nbase + TPF * m]; nv[m] = v[nbase + TPF * m]; np[m] = p[nbase + TPF * m]; }
+            }
+        };
         C2<float> a[16], b[16];
-        deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k);
-        float pu[16], pv[16], pd[16];
+        deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k, hook);
+        // epilogue in two halves (bounds the registers in flight next to the prefetched line): u_prev, v_prev and the
+        // x-pass partials in, residuals out
 #pragma unroll
-        for (int m = 0; m < 16; ++m) { pu[m] = ru[base + TPF * m]; pv[m] = rv[base + TPF * m]; pd[m] = rd[base + TPF * m]; }
-        if (valid) {
+        for (int h = 0; h < 2; ++h) {
+            float pu[8], pv[8], pd[8], qu[8], qv[8];
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const size_t c = base + TPF * m;
-                ru[c] = du[m] + pu[m] + vf[m] * a[m].x + b[m].x;
-                rv[c] = dv[m] + pv[m] + vf[m] * a[m].y + b[m].y;
-                rd[c] = pd[m] + a[m].y;
+            for (int i = 0; i < 8; ++i) {
+                const size_t c = base + TPF * (8 * h + i);
+                pu[i] = ru[c]; pv[i] = rv[c]; pd[i] = rd[c]; qu[i] = up[c]; qv[i] = vp[c];
+            }
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = 8 * h + i;
+                    const size_t c = base + TPF * m;
+                    ru[c] = (uf[m] - qu[i]) * k.inv_dt + pu[i] + vf[m] * a[m].x + b[m].x;
+                    rv[c] = (vf[m] - qv[i]) * k.inv_dt + pv[i] + vf[m] * a[m].y + b[m].y;
+                    rd[c] = pd[i] + a[m].y;
+                }
             }
         }
     }
