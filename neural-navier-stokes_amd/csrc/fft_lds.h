@@ -27,6 +27,12 @@ namespace nns {
 
 template <typename T> struct C2 { T x, y; };
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, I1)
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
+}
+
 template <typename T> __device__ __forceinline__ C2<T> operator+(C2<T> a, C2<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> __device__ __forceinline__ C2<T> operator-(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }
 template <typename T> __device__ __forceinline__ C2<T> cmul(C2<T> a, C2<T> b) {
@@ -139,7 +145,7 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
     asm volatile("" : "+v"(tid), "+v"(x[0].x));
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-        const int j = tid + TPF * q;
+        const unsigned j = (unsigned)tid + TPF * q;
         C2<T> y[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) y[t] = x[q + NB * t];
@@ -153,7 +159,7 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
             // second pass: twiddle W_N^{t * c * N/(16 R)}, c = j mod 16, from the pass-2 table laid out [t][c]:
             // for a given t the lanes of a wave read 16 CONSECUTIVE entries (conflict-free, broadcast across
             // the lane groups that share c); striding the main table by t*c*N/(16R) was up to 16-way conflicted.
-            int c = j & 15;
+            int c = (int)(j & 15u);
             if constexpr (sizeof(T) == 8 && !NNS_TW_LOOKUP) {
                 // float64: ONE table read, the other R-2 twiddles by running product (14 roundings of 1e-16 are
                 // irrelevant, and 15 hoisted double2 reads would cost 60 VGPRs).  Grouped table reads (pinned
@@ -176,7 +182,7 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
                 }
             }
         } else if constexpr (NS > 1) {
-            int jm = (j & (NS - 1)) * (N / (NS * R));
+            int jm = (int)((j & (unsigned)(NS - 1)) * (unsigned)(N / (NS * R)));
             if constexpr (sizeof(T) == 8 && !NNS_TW_LOOKUP) {
                 const C2<T> w = twiddle<T, N, INV>(tab, jm);
                 C2<T> wt = w;
@@ -196,16 +202,20 @@ __device__ __forceinline__ void fft_pass(C2<T> (&x)[16], const C2<T>* __restrict
 #pragma unroll
             for (int s = 0; s < R; ++s) x[q + NB * s] = y[s];
         } else {
-            const int e0 = (j / NS) * (NS * R) + (j & (NS - 1));
+            // slot(e0 + s NS) = slot(e0) + slot(s NS): s NS is a multiple of 16 or (NS = 1) e0 is: one base + constants
+            const unsigned e0 = (j / NS) * (NS * R) + (j & (unsigned)(NS - 1));
+            const unsigned wbase = e0 + (e0 >> 4);
 #pragma unroll
-            for (int s = 0; s < R; ++s) xb[fft_slot(e0 + s * NS)] = y[s];
+            for (int s = 0; s < R; ++s) xb[wbase + (unsigned)fft_slot(s * NS)] = y[s];
         }
     }
     if constexpr (!LAST) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // slot(tid + TPF m) = slot(tid) + slot(TPF m): TPF m is a multiple of 16, or tid + (TPF m mod 16) < 16
+        const unsigned rbase = (unsigned)tid + ((unsigned)tid >> 4);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) x[m] = xb[fft_slot(tid + TPF * m)];
+        for (int m = 0; m < 16; ++m) x[m] = xb[rbase + (unsigned)fft_slot(TPF * m)];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

@@ -39,8 +39,10 @@ constexpr int kSpecThreads = 512;                  // 8 waves: 2 per SIMD, <= 25
 constexpr int kSpecWaves = kSpecThreads / kWave;
 
 struct SpecK {
-    double kscale;        // 2 pi / L for the transformed axis
-    double inv_rho, nu, inv_n;
+    // folded on the host (kscale = 2 pi / L of the transformed axis, 1/N = the inverse transform's normalisation):
+    double c1;            // kscale / N            : first-derivative factor per unit wavenumber index
+    double cs;            // kscale / (rho N)      : pressure-gradient factor per unit wavenumber index
+    double c2;            // nu kscale^2 / N       : viscous factor per unit SQUARED wavenumber index
     float inv_dt;
 };
 
@@ -61,12 +63,14 @@ struct SpecLds {
     static constexpr int TOTAL = TABF_BYTES + TABI_BYTES + LINES * LINE_BYTES;
 };
 
-// signed wavenumber index of element e: (odd-derivative k [Nyquist -> 0], k for even derivatives)
-template <int N>
-__device__ __forceinline__ void wavenumber(int e, int& k_odd, int& k_even) {
-    const int k = e < N / 2 ? e : e - N;
-    k_even = k;
-    k_odd = (e == N / 2) ? 0 : k;
+// Signed wavenumber index of the element in register slot m of lane `te` (element te + TPF m).  N/2 = 8 TPF, so
+// slots 0..7 hold the non-negative wavenumbers and 8..15 the negative ones: no compare except for the Nyquist mode
+// (slot 8 of lane 0), which odd derivatives drop, as in the oracle.
+template <int N, int M>
+__device__ __forceinline__ void wavenumber(int te, int& k_odd, int& k_even) {
+    constexpr int TPF = N / 16;
+    k_even = te + TPF * M - (M >= 8 ? N : 0);
+    if constexpr (M == 8) k_odd = te == 0 ? 0 : k_even; else k_odd = k_even;
 }
 
 // The shared core: from the line's u, v, p (element tid + TPF*m in slot m) produce
@@ -94,14 +98,14 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     // transform's output so they are computed here, where they are used.
     int te = tid;
     asm volatile("" : "+v"(te), "+v"(z[0].x));
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
         int ko, ke;
-        wavenumber<N>(te + TPF * m, ko, ke);
-        const TF s = (TF)((double)ko * k.kscale * k.inv_rho * k.inv_n);
+        wavenumber<N, m>(te, ko, ke);
+        const TF s = (TF)((double)ko * k.cs);
         if constexpr (P_IN_REAL) { b[m].x = (float)(-s * z[m].y); b[m].y = (float)(s * z[m].x); }   // (i k/rho) Z2
         else { b[m].x = (float)(-s * z[m].x); b[m].y = (float)(-s * z[m].y); }                       // i (i k/rho) Z2
-    }
+    });
     __builtin_amdgcn_sched_barrier(0);
     // ---- velocity: Z1 = FFT(u + i v)
 #pragma unroll
@@ -109,16 +113,15 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     fft_line<TF, N, false, P>(z, tabF, tabF2, xbF, tid, hook);
     te = tid;
     asm volatile("" : "+v"(te), "+v"(z[0].x));
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
         int ko, ke;
-        wavenumber<N>(te + TPF * m, ko, ke);
-        const TF k1 = (TF)((double)ko * k.kscale * k.inv_n);
-        const double kk = (double)ke * k.kscale;
-        const TF k2 = (TF)(k.nu * kk * kk * k.inv_n);
+        wavenumber<N, m>(te, ko, ke);
+        const TF k1 = (TF)((double)ko * k.c1);
+        const TF k2 = (TF)((double)(ke * ke) * k.c2);                         // ke^2 <= 2^18: exact
         a[m].x = (float)(-k1 * z[m].y); a[m].y = (float)(k1 * z[m].x);        // i k Z1
         b[m].x += (float)(k2 * z[m].x); b[m].y += (float)(k2 * z[m].y);       // nu k^2 Z1
-    }
+    });
     // ---- inverse transforms in float32
     __builtin_amdgcn_sched_barrier(0);
     fft_line<float, N, true, 2 * P>(a, tabI, tabI2, xbI, tid, hook);
@@ -426,7 +429,8 @@ int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, 
     if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
     if (!pow2_in_range(nx)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_xpass: nx=%d must be a power of two in [64, 1024]", nx);
     if (Lx == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: Lx, rho must be non-zero");
-    SpecK k{2.0 * M_PI / Lx, 1.0 / rho, nu, 1.0 / nx, 0.f};
+    const double ks = 2.0 * M_PI / Lx;
+    SpecK k{ks / nx, ks / (rho * nx), nu * ks * ks / nx, 0.f};
     return dispatch_n(nx, [&](auto n) {
         constexpr int N = decltype(n)::value;
         return precise ? launch_xpass<N, double>(u, v, p, ru, rv, rd, batch, ny, k, s)
@@ -439,7 +443,8 @@ int ypass(const float* u, const float* v, const float* p, const float* up, const
     if (!u || !v || !p || !up || !vp || !ru || !rv || !rd || batch < 1 || nx < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_ypass: bad args");
     if (!pow2_in_range(ny)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_ypass: ny=%d must be a power of two in [64, 1024]", ny);
     if (Ly == 0 || rho == 0 || dt == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_ypass: Ly, rho, dt must be non-zero");
-    SpecK k{2.0 * M_PI / Ly, 1.0 / rho, nu, 1.0 / ny, (float)(1.0 / dt)};
+    const double ks = 2.0 * M_PI / Ly;
+    SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const long nrows = (long)batch * nx;
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
