@@ -23,6 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#ifndef NNS_DFT_SB
+#define NNS_DFT_SB 1      // scheduling barriers between the dft4 groups of a float64 dft16 (bounds register pressure)
+#endif
+
 namespace nns {
 
 template <typename T> struct C2 { T x, y; };
@@ -77,7 +81,7 @@ __device__ __forceinline__ void dft16(C2<T> (&x)[16]) {
 #pragma unroll
     for (int n2 = 0; n2 < 4; ++n2) {
         dft4<T, INV>(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);   // k1 at x[4*k1+n2]
-        if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (sizeof(T) == 8 && NNS_DFT_SB) __builtin_amdgcn_sched_barrier(0);
     }
     // x[4*k1 + n2] *= W16^{n2*k1}
     x[5] = mulw<T, INV>(x[5], c1, s1);      // 1
@@ -92,7 +96,7 @@ __device__ __forceinline__ void dft16(C2<T> (&x)[16]) {
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) {
         dft4<T, INV>(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);  // k2 at x[4*k1+k2]
-        if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (sizeof(T) == 8 && NNS_DFT_SB) __builtin_amdgcn_sched_barrier(0);
     }
     // y[k1 + 4*k2] = x[4*k1 + k2]: 4x4 transpose
 #pragma unroll

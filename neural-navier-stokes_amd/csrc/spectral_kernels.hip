@@ -35,7 +35,10 @@ using namespace nns;
 
 namespace {
 
-constexpr int kSpecThreads = 512;                  // 8 waves: 2 per SIMD, <= 256 VGPRs each
+#ifndef NNS_SPEC_THREADS
+#define NNS_SPEC_THREADS 512
+#endif
+constexpr int kSpecThreads = NNS_SPEC_THREADS;      // 8 waves: 2 per SIMD, <= 256 VGPRs each
 constexpr int kSpecWaves = kSpecThreads / kWave;
 
 struct SpecK {
