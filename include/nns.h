@@ -214,6 +214,16 @@ int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* 
 int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const float* biases, float* y, int mb, int P,
                           const int* widths_host, int nlayers, int bf16, void* stream);
 
+/* Its backward (what autograd would do for the reference's Conv2d/ReLU stack, spectral_ode.py:100-119), fused in one
+ * launch that recomputes the forward in registers: gy [mb, widths[nlayers], P] -> gx [mb, widths[0], P], gW / gB packed
+ * like weights / biases (overwritten).  bf16 mode only (bf16 == 0: NNS_ERR_UNSUPPORTED): operands rounded to bfloat16
+ * exactly as the forward does, float32 accumulation; weight gradients contract over pixels with transposing LDS reads
+ * and are reduced over workgroups in a fixed order.  workspace: nns_pixel_mlp_bwd_workspace bytes of device memory. */
+int nns_pixel_mlp_bwd_workspace(const int* widths_host, int nlayers, size_t* bytes);
+int nns_pixel_mlp_bwd_f32(const float* x, const float* gy, const float* weights, const float* biases,
+                          float* gx, float* gW, float* gB, int mb, int P, const int* widths_host, int nlayers, int bf16,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- chorin_spectral (Chebyshev collocation): src/chorin_spectral/simulate.py ---------------- */
 /* Row-major float64 GEMM on the matrix cores: C = alpha * op(A) op(B) + beta * C, op = transpose when the flag is
  * set; `batch` independent problems stored back to back.  Replaces the `@` products of _predictor_step

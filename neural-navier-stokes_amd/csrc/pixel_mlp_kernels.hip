@@ -146,6 +146,273 @@ __global__ __launch_bounds__(256) void pixel_mlp_fwd_kernel(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward (bfloat16 operands, float32 accumulation).  One launch computes, for the same stack,
+//     gx = dL/dx,   gW_l = sum_pix delta_l a_{l-1}^T,   gb_l = sum_pix delta_l          given gy = dL/dy,
+// WITHOUT activations saved by the forward: a workgroup (4 waves, one 32-pixel tile each = a 128-pixel super-tile)
+// recomputes the forward in registers, keeping every layer's INPUT as the bf16 operand fragments the forward MFMAs
+// consumed (16 VGPRs per 64-channel layer), then walks the layers backwards:
+//   * data chain   delta_{l-1}^T[in x pix] = W_l^T[in x out] delta_l^T[out x pix]  -- the same accumulator-as-operand
+//     chaining as the forward, with fragments of W^T staged in LDS; ReLU mask from the stored fragments' sign;
+//   * weight grads sum over the PIXEL index, which sits on the lanes of both delta_l and a_{l-1}: one transpose is
+//     unavoidable.  Each wave stores its tiles as bf16 rows of two [128 pix][64 ch] LDS images (8-byte stores) and,
+//     after a barrier, every wave owns one 32x32 block of gW_l (out block = wave>>1, in block = wave&1) and reads its
+//     A = delta and B = activation fragments over all 128 pixels with ds_read_b64_tr_b16 (hardware transpose): 8 MFMAs
+//     per layer, accumulated in registers across all super-tiles of the workgroup (16 VGPRs per layer);
+//   * bias grads   from the delta fragments the in-block-0 waves read anyway (VALU adds beside the MFMAs).
+// Per layer and tile: 8 (forward) + 8 (data) + 8 (weights) MFMA 32x32x16 = the minimum.  Partial gradients go to a
+// per-workgroup workspace slice; pixel_mlp_reduce_kernel adds the slices in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------------------------
+using bf16x4 = __attribute__((ext_vector_type(4))) short;
+constexpr int kImgStride = 144;                 // bytes per pixel row of an exchange image: 64 ch * 2 B + 16 B pad
+constexpr int kImgBytes = 128 * kImgStride;
+
+struct PixelMlpBwdDesc {
+    PixelMlpDesc f;                              // forward fragments + biases
+    int lds_wt[kMaxLayers];                      // offset (bytes) of the W^T fragments
+    int lds_img_d, lds_img_a;                    // exchange images
+    int nparams_w, nparams;                      // packed weight count, weight + bias count
+};
+
+// fragments of W^T for the data chain: [it = in/32][s = out/16][lane 64][8] bf16 = W[16 s + 8 (j>>2) + 4 (lane>>5) + (j&3)][32 it + (lane&31)]
+__device__ void stage_weights_t(const PixelMlpBwdDesc& d, const float* __restrict__ W, unsigned char* lds, int tid, int nthreads) {
+    for (int l = 0; l < d.f.nlayers; ++l) {
+        const int cin = d.f.cin[l], cout = d.f.cout[l];
+        const int its = (cin + 31) / 32, ss = (cout + 15) / 16;
+        const float* Wl = W + d.f.woff[l];
+        unsigned short* dst = reinterpret_cast<unsigned short*>(lds + d.lds_wt[l]);
+        for (int e = tid; e < its * ss * 64 * 8; e += nthreads) {
+            const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) % ss, it = (e >> 9) / ss;
+            const int row = 32 * it + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+            dst[e] = f2bf((row < cin && k < cout) ? Wl[k * cin + row] : 0.f);
+        }
+    }
+}
+
+__device__ __forceinline__ float bf2f(short b) { return __builtin_bit_cast(float, (unsigned)(unsigned short)b << 16); }
+
+// 8 consecutive pixels (pix0 .. pix0+7, pix0 = 16 s + 8 (lane>>5)) of channel  ch_block + (lane&31)  from a [pix][ch] image:
+// two transposing reads of 4 pixel rows each.  Lane 4q+p of a 16-lane group addresses row q, channels 4p..4p+3 of the
+// group's 4 x 16 block; lane i receives channel i of the four rows.  EXEC must be all ones here.
+__device__ __forceinline__ bf16x8 read_tr8(const unsigned char* img, int lane, int s, int ch_block) {
+    const int gl = lane & 15, q = gl >> 2, pp = gl & 3;
+    const int ch0 = ch_block + 16 * ((lane >> 4) & 1), pix0 = 16 * s + 8 * (lane >> 5);
+    const unsigned char* a0 = img + (pix0 + q) * kImgStride + (ch0 + 4 * pp) * 2;
+    using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * kImgStride));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void pixel_mlp_bwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                  const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                  float* __restrict__ gx, float* __restrict__ ws,
+                                                                  long npix_total, int P, PixelMlpBwdDesc d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    stage_weights<true>(d.f, W, Bv, lds, threadIdx.x, 256);
+    stage_weights_t(d, W, lds, threadIdx.x, 256);
+    unsigned char* imgD = lds + d.lds_img_d;
+    unsigned char* imgA = lds + d.lds_img_a;
+    for (int e = threadIdx.x; e < 2 * kImgBytes / 4; e += 256) reinterpret_cast<unsigned*>(imgD)[e] = 0u;   // images are contiguous; pads stay 0
+    __syncthreads();
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
+    const int bo = wave >> 1, bi = wave & 1;
+    const int nl = d.f.nlayers;
+    const int cin0 = d.f.cin[0], coutL = d.f.cout[nl - 1];
+
+    f32x16 gw[kMaxLayers];
+    float gbp[kMaxLayers];
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        gbp[l] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gw[l][i] = 0.f;
+    }
+    const long nsuper = (npix_total + 127) / 128;
+    for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+        const long gp = sup * 128 + wave * 32 + r;
+        const bool ok = gp < npix_total;
+        const long b = ok ? gp / P : 0, p = ok ? gp % P : 0;
+        // ---------------- forward, keeping every layer's input fragments
+        bf16x8 afrag[kMaxLayers][4];
+        f32x16 act[2];
+        {
+            const float* xb = x + (size_t)b * cin0 * P + p;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); act[t][i] = (ok && c < cin0) ? xb[(size_t)c * P] : 0.f; }
+        }
+#pragma unroll
+        for (int l = 0; l < kMaxLayers; ++l) {
+            if (l < nl) {
+                const int cin = d.f.cin[l], cout = d.f.cout[l];
+                const int ots = (cout + 31) / 32, ss = (cin + 15) / 16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) afrag[l][s][j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
+                if (l + 1 < nl) {                                            // the last layer's output is not needed
+                    const float* bl = reinterpret_cast<const float*>(lds + d.f.lds_bias[l]);
+                    const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds + d.f.lds_off[l]);
+                    f32x16 out[2];
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot) {
+                        if (ot < ots) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) out[ot][i] = bl[32 * ot + acc_row(i, h)];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                if (s < ss) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ot * ss + s) * 64 + lane], afrag[l][s], out[ot], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) out[ot][i] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) act[t][i] = fmaxf(out[t][i], 0.f);
+                }
+            }
+        }
+        // ---------------- backward
+        f32x16 dl[2];
+        {
+            const float* gb = gy + (size_t)b * coutL * P + p;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); dl[t][i] = (ok && c < coutL) ? gb[(size_t)c * P] : 0.f; }
+        }
+#pragma unroll
+        for (int l = kMaxLayers - 1; l >= 0; --l) {
+            if (l < nl) {
+                const int cin = d.f.cin[l], cout = d.f.cout[l];
+                // delta_l and a_{l-1} as bf16 rows [32 wave + r] of the images
+                bf16x8 dfrag[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dfrag[s][j] = (short)f2bf(dl[s >> 1][8 * (s & 1) + j]);
+                {
+                    unsigned char* rowD = imgD + (32 * wave + r) * kImgStride;
+                    unsigned char* rowA = imgA + (32 * wave + r) * kImgStride;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        // fragment elements 0..3 = channels 16 s + 4 h + (0..3), elements 4..7 = channels 16 s + 8 + 4 h + (0..3)
+                        bf16x4 d0, d1, a0, a1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { d0[j] = dfrag[s][j]; d1[j] = dfrag[s][4 + j]; a0[j] = afrag[l][s][j]; a1[j] = afrag[l][s][4 + j]; }
+                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 4 * h) * 2) = d0;
+                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 8 + 4 * h) * 2) = d1;
+                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 4 * h) * 2) = a0;
+                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = a1;
+                    }
+                }
+                __syncthreads();
+                if (32 * bo < cout && 32 * bi < cin) {                       // wave-uniform: EXEC stays full for the transposing reads
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const bf16x8 fa = read_tr8(imgD, lane, s, 32 * bo);
+                        const bf16x8 fb = read_tr8(imgA, lane, s, 32 * bi);
+                        gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                        if (bi == 0) {
+                            float sum = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) sum += bf2f(fa[j]);
+                            gbp[l] += sum;
+                        }
+                    }
+                }
+                __syncthreads();
+                // data chain: delta_{l-1} (or gx for l = 0)
+                {
+                    const int its = (cin + 31) / 32, ss = (cout + 15) / 16;
+                    const bf16x8* wt = reinterpret_cast<const bf16x8*>(lds + d.lds_wt[l]);
+                    f32x16 nd[2];
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
+                        if (it < its) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                if (s < ss) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[(it * ss + s) * 64 + lane], dfrag[s], nd[it], 0, 0, 0);
+                        }
+                    }
+                    if (l > 0) {
+                        // ReLU mask: a_{l-1} > 0, read off the stored fragments (register i of tile t = element i&7 of fragment 2t + (i>>3))
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) dl[t][i] = afrag[l][2 * t + (i >> 3)][i & 7] > 0 ? nd[t][i] : 0.f;
+                    } else if (ok) {
+                        float* gxb = gx + (size_t)b * cin0 * P + p;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); if (c < cin0) gxb[(size_t)c * P] = nd[t][i]; }
+                    }
+                }
+            }
+        }
+    }
+    // ---------------- this workgroup's partial gradients
+    float* wsb = ws + (size_t)blockIdx.x * d.nparams;
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        if (l < nl) {
+            const int cin = d.f.cin[l], cout = d.f.cout[l];
+            const int in = 32 * bi + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int out = 32 * bo + acc_row(i, h);
+                if (out < cout && in < cin) wsb[d.f.woff[l] + out * cin + in] = gw[l][i];
+            }
+            if (bi == 0) {
+                const float tot = gbp[l] + __shfl_xor(gbp[l], 32);
+                if (h == 0 && 32 * bo + r < cout) wsb[d.nparams_w + d.f.boff[l] + 32 * bo + r] = tot;
+            }
+        }
+    }
+}
+
+__global__ void pixel_mlp_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gB, int nslices, int nparams_w, int nparams) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nparams) return;
+    float acc = 0.f;
+    for (int k = 0; k < nslices; ++k) acc += ws[(size_t)k * nparams + i];
+    if (i < nparams_w) gW[i] = acc; else gB[i - nparams_w] = acc;
+}
+
+constexpr int kBwdMaxBlocks = 256;
+
+int build_bwd_desc(const int* widths_host, int nlayers, PixelMlpBwdDesc& d, int& lds_total) {
+    if (nlayers < 1 || nlayers > kMaxLayers) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: %d layers (1..%d supported)", nlayers, kMaxLayers);
+    d.f.nlayers = nlayers;
+    int woff = 0, boff = 0, lds = 0;
+    for (int l = 0; l < kMaxLayers; ++l) { d.f.cin[l] = d.f.cout[l] = 1; d.f.woff[l] = d.f.boff[l] = d.f.lds_off[l] = d.f.lds_bias[l] = 0; d.lds_wt[l] = 0; }
+    for (int l = 0; l < nlayers; ++l) {
+        const int cin = widths_host[l], cout = widths_host[l + 1];
+        if (cin < 1 || cout < 1 || cin > kMaxWidth || cout > kMaxWidth) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: layer %d is %d -> %d (widths 1..%d supported)", l, cin, cout, kMaxWidth);
+        d.f.cin[l] = cin; d.f.cout[l] = cout; d.f.woff[l] = woff; d.f.boff[l] = boff;
+        woff += cin * cout; boff += cout;
+        d.f.lds_off[l] = lds;  lds += ((cout + 31) / 32) * ((cin + 15) / 16) * 64 * 16;
+        d.f.lds_bias[l] = lds; lds += ((cout + 31) / 32) * 32 * 4;
+        d.lds_wt[l] = lds;     lds += ((cin + 31) / 32) * ((cout + 15) / 16) * 64 * 16;
+    }
+    d.lds_img_d = lds; lds += kImgBytes;
+    d.lds_img_a = lds; lds += kImgBytes;
+    d.nparams_w = woff; d.nparams = woff + boff;
+    lds_total = lds;
+    if (lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: needs %d B of LDS (> 160 KiB)", lds);
+    return NNS_OK;
+}
+
 }  // namespace
 
 // x [mb, C_in, P], y [mb, C_out, P] (NCHW with P = nx*ny, as the reference's Conv2d stack); weights packed layer after
@@ -187,4 +454,37 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
         hipLaunchKernelGGL(pixel_mlp_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, x, weights, biases, y, npix, P, d);
     }
     return check_launch("pixel_mlp_fwd");
+}
+
+// Backward of nns_pixel_mlp_fwd_f32 in its bf16 mode (see the kernel comment).  gy [mb, C_out, P] in; gx [mb, C_in, P],
+// gW (packed like weights) and gB (packed like biases) out -- overwritten, not accumulated.  The float32-operand mode has
+// no backward yet: bf16 == 0 fails with NNS_ERR_UNSUPPORTED.
+NNS_API int nns_pixel_mlp_bwd_workspace(const int* widths_host, int nlayers, size_t* bytes) {
+    if (!widths_host || !bytes) return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd_workspace: bad args");
+    PixelMlpBwdDesc d; int lds;
+    if (int rc = build_bwd_desc(widths_host, nlayers, d, lds)) return rc;
+    *bytes = (size_t)kBwdMaxBlocks * d.nparams * sizeof(float);
+    return NNS_OK;
+}
+
+NNS_API int nns_pixel_mlp_bwd_f32(const float* x, const float* gy, const float* weights, const float* biases,
+                                  float* gx, float* gW, float* gB, int mb, int P, const int* widths_host, int nlayers, int bf16,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !gy || !weights || !biases || !gx || !gW || !gB || !widths_host || !workspace || mb < 1 || P < 1)
+        return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: bad args");
+    if (!bf16) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: only the bf16 mode has a backward kernel");
+    PixelMlpBwdDesc d; int lds;
+    if (int rc = build_bwd_desc(widths_host, nlayers, d, lds)) return rc;
+    if (workspace_bytes < (size_t)kBwdMaxBlocks * d.nparams * sizeof(float))
+        return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: workspace too small (%zu B, see nns_pixel_mlp_bwd_workspace)", workspace_bytes);
+    const long npix = (long)mb * P;
+    const long nsuper = (npix + 127) / 128;
+    const int blocks = (int)(nsuper < kBwdMaxBlocks ? nsuper : kBwdMaxBlocks);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(pixel_mlp_bwd_bf16_kernel, dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, static_cast<float*>(workspace), npix, P, d);
+    if (int rc = check_launch("pixel_mlp_bwd")) return rc;
+    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((d.nparams + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), gW, gB, blocks, d.nparams_w, d.nparams);
+    return check_launch("pixel_mlp_reduce");
 }

@@ -86,7 +86,6 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
                                            const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid,
                                            const SpecK& k, Hook&& hook = Hook{}) {
     constexpr int P = FftPasses<N>::value;
-    constexpr int TPF = N / 16;
     const C2<TF>* tabF2 = tabF + N / 2;
     const C2<float>* tabI2 = tabI + N / 2;
     C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);

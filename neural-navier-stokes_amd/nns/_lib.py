@@ -49,6 +49,8 @@ _SINGLE = {
     'nns_spec_rfft2_f32': [_P, _P, _I, _I, _I, _P],
     'nns_spec_irfft2_f32': [_P, _P, _I, _I, _I, _P],
     'nns_pixel_mlp_fwd_f32': [_P] * 4 + [_I, _I, C.POINTER(C.c_int), _I, _I, _P],
+    'nns_pixel_mlp_bwd_workspace': [C.POINTER(C.c_int), _I, C.POINTER(C.c_size_t)],
+    'nns_pixel_mlp_bwd_f32': [_P] * 7 + [_I, _I, C.POINTER(C.c_int), _I, _I, _P, C.c_size_t, _P],
     'nns_cheb_gemm_f64': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _D, _D, _I, _P],
     'nns_cheb_helmholtz_rhs_f64': [_P] * 12 + [_I, _D, _P],
     'nns_cheb_diag_div_f64': [_P] * 4 + [_I, _I, _D, _D, _D, _P],

@@ -172,8 +172,14 @@ class PixelMLP(nn.Module):
         self.biases = nn.ParameterList([nn.Parameter(torch.zeros(dims[i + 1])) for i in range(depth)])
 
     def forward(self, grid, bf16=False):
+        """Inference (no autograd graph); `train_forward` is the differentiable bf16 path."""
         with torch.no_grad():
             return ops.pixel_mlp_fwd(grid.contiguous(), list(self.weights), list(self.biases), bf16=bf16)
+
+    def train_forward(self, grid):
+        """bf16-operand forward recorded as ONE autograd node whose backward is the fused HIP kernel
+        (nns_pixel_mlp_bwd_f32: forward recomputed in registers, no saved activations)."""
+        return ops.PixelMlpFn.apply(grid.contiguous(), len(self.weights), *self.weights, *self.biases)
 
 
 class AverageMeter(object):

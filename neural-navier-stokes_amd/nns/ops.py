@@ -323,6 +323,61 @@ def pixel_mlp_fwd(x, weights, biases, bf16=False):
     return y
 
 
+def _pixel_mlp_pack(x, weights, biases, what):
+    _f32(x)
+    mb, cin = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    ws = [w.reshape(w.shape[0], w.shape[1]) for w in weights]
+    widths = [cin] + [w.shape[0] for w in ws]
+    for i, w in enumerate(ws):
+        if w.shape[1] != widths[i]:
+            raise ValueError("%s: layer %d expects %d input channels, got %d" % (what, i, w.shape[1], widths[i]))
+    wp = torch.cat([w.reshape(-1) for w in ws]).to(torch.float32).contiguous()
+    bp = torch.cat([b.reshape(-1) for b in biases]).to(torch.float32).contiguous()
+    return mb, P, ws, widths, wp, bp
+
+
+def pixel_mlp_bwd(x, gy, weights, biases, bf16=True):
+    """Backward of pixel_mlp_fwd (bf16 mode): returns (gx like x, [gW_l like weights[l]], [gb_l like biases[l]])."""
+    import ctypes
+    mb, P, ws, widths, wp, bp = _pixel_mlp_pack(x, weights, biases, 'pixel_mlp_bwd')
+    _f32(gy)
+    if tuple(gy.shape) != (mb, widths[-1]) + tuple(x.shape[2:]):
+        raise ValueError("pixel_mlp_bwd: gy has shape %s, expected %s" % (tuple(gy.shape), (mb, widths[-1]) + tuple(x.shape[2:])))
+    arr = (ctypes.c_int * len(widths))(*widths)
+    nbytes = ctypes.c_size_t(0)
+    check(_lib.lib().nns_pixel_mlp_bwd_workspace(arr, len(ws), ctypes.byref(nbytes)), 'nns_pixel_mlp_bwd_workspace')
+    work = torch.empty(max(nbytes.value // 4, 1), dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x)
+    gW = torch.empty_like(wp)
+    gB = torch.empty_like(bp)
+    check(_lib.lib().nns_pixel_mlp_bwd_f32(_p(x), _p(gy), _p(wp), _p(bp), _p(gx), _p(gW), _p(gB), mb, P, arr, len(ws), int(bool(bf16)),
+                                           _p(work), nbytes.value, _stream()), 'nns_pixel_mlp_bwd_f32')
+    gws, gbs, wo, bo = [], [], 0, 0
+    for w, b in zip(weights, biases):
+        gws.append(gW[wo:wo + w.numel()].reshape(w.shape)); wo += w.numel()
+        gbs.append(gB[bo:bo + b.numel()].reshape(b.shape)); bo += b.numel()
+    return gx, gws, gbs
+
+
+class PixelMlpFn(torch.autograd.Function):
+    """pixel_mlp_fwd / pixel_mlp_bwd as one autograd node (bf16 operands, float32 accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, nlayers, *params):
+        weights, biases = params[:nlayers], params[nlayers:]
+        ctx.nlayers = nlayers
+        ctx.save_for_backward(x, *params)
+        return pixel_mlp_fwd(x, weights, biases, bf16=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, *params = ctx.saved_tensors
+        weights, biases = params[:ctx.nlayers], params[ctx.nlayers:]
+        gx, gws, gbs = pixel_mlp_bwd(x.contiguous(), gy.contiguous(), weights, biases, bf16=True)
+        return (gx, None) + tuple(gws) + tuple(gbs)
+
+
 # ----------------------------------------------------------------------------- standalone spectral operators
 def spec_derivs(f, Lx, Ly, want=('x', 'y', 'lap'), precise=True):
     """Spectral f_x, f_y, lap f of one real float32 field [B, nx, ny] (or [nx, ny]); returns a dict."""

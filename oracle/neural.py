@@ -88,6 +88,37 @@ def diversity_penalty(basis):
     return 1. / tot
 
 
+def _bf16_round(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def pixel_mlp_backward(weights, biases, grid, gy, bf16=False):
+    """Reverse-mode of pixel_mlp by hand (what autograd does for the Conv2d/ReLU stack of :100-119):
+    returns (gx, [gW_l], [gb_l]).  Used to check the fused HIP backward; itself checked against autograd.
+    bf16=True emulates the kernel's operand rounding (weights, layer inputs and deltas to bfloat16 before every
+    product, exact accumulation, ReLU mask from the rounded layer input) so that the comparison can be tight."""
+    rnd = _bf16_round if bf16 else (lambda t: t)
+    L = len(weights)
+    Wr = [rnd(W) for W in weights]
+    ins = []
+    h = grid
+    for l in range(L):
+        ins.append(rnd(h))
+        h = torch.einsum('oc,bcxy->boxy', Wr[l], ins[l]) + biases[l][None, :, None, None]
+        if l < L - 1:
+            h = torch.relu(h)
+    d = gy
+    gWs, gbs = [None] * L, [None] * L
+    for l in range(L - 1, -1, -1):
+        dr = rnd(d)
+        gWs[l] = torch.einsum('boxy,bcxy->oc', dr, ins[l])
+        gbs[l] = dr.sum(dim=(0, 2, 3))
+        d = torch.einsum('oc,boxy->bcxy', Wr[l], dr)
+        if l > 0:
+            d = d * (ins[l] > 0).to(d.dtype)
+    return d, gWs, gbs
+
+
 def pixel_mlp(weights, biases, grid):
     """BasisFunc (:100-119) generalised to any depth: 1x1 convs == per-pixel linears with ReLU
     between layers, none after the last.  weights[l] [C_out, C_in]; grid [mb, C_in0, nx, ny]."""
