@@ -85,6 +85,12 @@ def cfg3():
         tm = timeit(lambda: mlp(x, bf16=bf), iters=10)
         flops = 2 * 16 * n * n * (3 * 64 + 6 * 64 * 64 + 64 * 3)
         out['pixel_mlp_d8_w64_%s' % ('bf16' if bf else 'fp32')] = dict(ms=1e3 * tm, Gpix_s=16 * n * n / tm / 1e9, TFLOPs=flops / tm / 1e12)
+    # fused backward (bf16): forward recompute + data chain + weight gradients = 3x the forward's flops
+    from nns import ops
+    gy = torch.randn_like(x)
+    ws, bs = [w.detach() for w in mlp.weights], [b.detach() for b in mlp.biases]
+    tb = timeit(lambda: ops.pixel_mlp_bwd(x, gy, ws, bs), iters=10)
+    out['pixel_mlp_d8_w64_bf16_backward'] = dict(ms=1e3 * tb, Gpix_s=16 * n * n / tb / 1e9, TFLOPs=3 * flops / tb / 1e12)
     return dict(config='cfg3 512x512 Re=1000: residual (FD5 + spectral, batch 64) + depth-8 width-64 pixel MLP',
                 residual_updates_per_s=B * n * n / tr, **out)
 

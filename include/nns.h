@@ -145,6 +145,17 @@ int nns_fd_residual_f64(const double* u, const double* v, const double* p, const
                         const double* v_prev, double* r_u, double* r_v, double* r_div,
                         int batch, int nx, int ny, double dt, double dx, double dy,
                         double rho, double nu, int stencil, void* stream);
+/* Vector-Jacobian product of the FD residual (the physics-informed loss' backward;
+ * oracle/periodic.py: fd_residual_vjp).  g_* = dLoss/dr_*; outputs dLoss/du, /dv, /dp and, when the pointers are
+ * non-null, dLoss/du_prev = -g_u/dt, dLoss/dv_prev = -g_v/dt.  Adjoint stencils (D^T = -D, L^T = L); p does not enter. */
+int nns_fd_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,
+                            float* grad_u, float* grad_v, float* grad_p, float* grad_u_prev, float* grad_v_prev,
+                            int batch, int nx, int ny, double dt, double dx, double dy,
+                            double rho, double nu, int stencil, void* stream);
+int nns_fd_residual_bwd_f64(const double* u, const double* v, const double* g_u, const double* g_v, const double* g_div,
+                            double* grad_u, double* grad_v, double* grad_p, double* grad_u_prev, double* grad_v_prev,
+                            int batch, int nx, int ny, double dt, double dx, double dy,
+                            double rho, double nu, int stencil, void* stream);
 /* Spectral back-end: d/dx <-> i kx, lap <-> -|k|^2 via LDS-resident 1-D FFTs (the operators are
  * separable, so no 2-D transform is materialised): pass 1 transforms columns (axis 0) and leaves
  * the x-part of the residual in r_u, r_v, r_div; pass 2 transforms rows (axis 1) and completes

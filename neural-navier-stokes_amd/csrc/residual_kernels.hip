@@ -226,6 +226,168 @@ int fd_residual(const T* u, const T* v, const T* p, const T* up, const T* vp, T*
     return check_launch("fd_residual");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward (vector-Jacobian product) of the FD residual: the adjoint stencils (oracle/periodic.py: residual_vjp).
+// With a = g_u, b = g_v, d = g_div (upstream gradients), D = central difference (D^T = -D), L = the 5/9-point
+// Laplacian (L^T = L):
+//   grad_u = a/dt + a u_x + b v_x - D_x(a u + d) - D_y(a v) - nu L a
+//   grad_v = b/dt + a u_y + b v_y - D_x(b u) - D_y(b v + d) - nu L b
+//   grad_p = -(D_x a + D_y b)/rho,     grad_u_prev = -a/dt,  grad_v_prev = -b/dt   (optional outputs)
+// Same design as the forward: 5 input streams (u, v, a, b, d) in a three-row rolling window, 3..5 output streams,
+// 16-byte lanes, j+-1 neighbours by shuffle; 32..40 B/pt of compulsory traffic, HBM-bound.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__device__ __forceinline__ T left_of(const Row<T, V>& r, int e) { return e == 0 ? r.l : r.v[e > 0 ? e - 1 : 0]; }
+template <typename T, int V>
+__device__ __forceinline__ T right_of(const Row<T, V>& r, int e) { return e == V - 1 ? r.r : r.v[e < V - 1 ? e + 1 : 0]; }
+
+template <typename T, int STENCIL>
+__global__ __launch_bounds__(256) void fd_residual_bwd_vec_kernel(const T* __restrict__ u, const T* __restrict__ v,
+                                                                   const T* __restrict__ ga, const T* __restrict__ gb, const T* __restrict__ gd,
+                                                                   T* __restrict__ gu, T* __restrict__ gv, T* __restrict__ gp,
+                                                                   T* __restrict__ gup, T* __restrict__ gvp,
+                                                                   int nx, int ny, int R, int nbands, int nstrips, ResK<T> k) {
+    constexpr int V = VecT<T>::V;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int strip = lb % nstrips, band = (lb / nstrips) % nbands, b = lb / (nstrips * nbands);
+    const int nvec = ny / V;
+    const int jv_raw = strip * 256 + (int)threadIdx.x;
+    const bool valid = jv_raw < nvec;
+    const int jv = valid ? jv_raw : nvec - 1;
+    const int j0 = jv * V;
+    const int jl = j0 == 0 ? ny - 1 : j0 - 1;
+    const int jr = j0 + V == ny ? 0 : j0 + V;
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool need_l = lane == 0;
+    const bool need_r = lane == kWave - 1 || jv_raw >= nvec - 1;
+    const size_t g = (size_t)b * nx * ny;
+    const T* ug = u + g; const T* vg = v + g; const T* ag = ga + g; const T* bg = gb + g; const T* dg = gd + g;
+    const int i0 = band * R, i1 = min(nx, i0 + R);
+    if (i0 >= nx) return;
+
+    // rows i-1, i, i+1 of u, v, a, b;  d only needs its vector on rows i+-1 and its l / r on row i
+    Row<T, V> um, uc, un, vm, vc, vn, am, ac, an, bm, bc, bn, dm, dc, dn;
+    {
+        const size_t rm = (size_t)(i0 == 0 ? nx - 1 : i0 - 1) * ny, rc = (size_t)i0 * ny;
+        load_row<T>(ug + rm, j0, jl, jr, need_l, need_r, um); load_row<T>(ug + rc, j0, jl, jr, need_l, need_r, uc);
+        load_row<T>(vg + rm, j0, jl, jr, need_l, need_r, vm); load_row<T>(vg + rc, j0, jl, jr, need_l, need_r, vc);
+        load_row<T>(ag + rm, j0, jl, jr, need_l, need_r, am); load_row<T>(ag + rc, j0, jl, jr, need_l, need_r, ac);
+        load_row<T>(bg + rm, j0, jl, jr, need_l, need_r, bm); load_row<T>(bg + rc, j0, jl, jr, need_l, need_r, bc);
+        load_row<T>(dg + rm, j0, jl, jr, need_l, need_r, dm); load_row<T>(dg + rc, j0, jl, jr, need_l, need_r, dc);
+    }
+    for (int i = i0; i < i1; ++i) {
+        const size_t rn = (size_t)(i + 1 == nx ? 0 : i + 1) * ny, rc = g + (size_t)i * ny + j0;
+        load_row<T>(ug + rn, j0, jl, jr, need_l, need_r, un);
+        load_row<T>(vg + rn, j0, jl, jr, need_l, need_r, vn);
+        load_row<T>(ag + rn, j0, jl, jr, need_l, need_r, an);
+        load_row<T>(bg + rn, j0, jl, jr, need_l, need_r, bn);
+        load_row<T>(dg + rn, j0, jl, jr, need_l, need_r, dn);
+        T o_u[V], o_v[V], o_p[V], o_up[V], o_vp[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T a = ac.v[e], bb = bc.v[e];
+            const T ul = left_of<T, V>(uc, e), ur = right_of<T, V>(uc, e), vl = left_of<T, V>(vc, e), vr = right_of<T, V>(vc, e);
+            const T al = left_of<T, V>(ac, e), ar = right_of<T, V>(ac, e), bl = left_of<T, V>(bc, e), br = right_of<T, V>(bc, e);
+            const T dl = left_of<T, V>(dc, e), dr = right_of<T, V>(dc, e);
+            const T ux = (un.v[e] - um.v[e]) * k.inv_2dx, uy = (ur - ul) * k.inv_2dy;
+            const T vx = (vn.v[e] - vm.v[e]) * k.inv_2dx, vy = (vr - vl) * k.inv_2dy;
+            // D_x(a u + d), D_y(a v), D_x(b u), D_y(b v + d), D_x a, D_y b
+            const T dx_aud = ((an.v[e] * un.v[e] + dn.v[e]) - (am.v[e] * um.v[e] + dm.v[e])) * k.inv_2dx;
+            const T dy_av = (ar * vr - al * vl) * k.inv_2dy;
+            const T dx_bu = (bn.v[e] * un.v[e] - bm.v[e] * um.v[e]) * k.inv_2dx;
+            const T dy_bvd = ((br * vr + dr) - (bl * vl + dl)) * k.inv_2dy;
+            const T dx_a = (an.v[e] - am.v[e]) * k.inv_2dx, dy_b = (br - bl) * k.inv_2dy;
+            double la = ((double)an.v[e] - 2.0 * a + (double)am.v[e]) * k.inv_dx2 + ((double)ar - 2.0 * a + (double)al) * k.inv_dy2;
+            double lb2 = ((double)bn.v[e] - 2.0 * bb + (double)bm.v[e]) * k.inv_dx2 + ((double)br - 2.0 * bb + (double)bl) * k.inv_dy2;
+            if constexpr (STENCIL == 9) {
+                la += k.c9 * (((double)left_of<T, V>(am, e) + right_of<T, V>(am, e) + left_of<T, V>(an, e) + right_of<T, V>(an, e))
+                              - 2.0 * ((double)am.v[e] + an.v[e] + al + ar) + 4.0 * a);
+                lb2 += k.c9 * (((double)left_of<T, V>(bm, e) + right_of<T, V>(bm, e) + left_of<T, V>(bn, e) + right_of<T, V>(bn, e))
+                               - 2.0 * ((double)bm.v[e] + bn.v[e] + bl + br) + 4.0 * bb);
+            }
+            o_u[e] = a * k.inv_dt + a * ux + bb * vx - dx_aud - dy_av - k.nu * (T)la;
+            o_v[e] = bb * k.inv_dt + a * uy + bb * vy - dx_bu - dy_bvd - k.nu * (T)lb2;
+            o_p[e] = -(dx_a + dy_b) * k.inv_rho;
+            o_up[e] = -a * k.inv_dt; o_vp[e] = -bb * k.inv_dt;
+        }
+        if (valid) {
+            store_vec<T>(gu + rc, o_u); store_vec<T>(gv + rc, o_v); store_vec<T>(gp + rc, o_p);
+            if (gup) store_vec<T>(gup + rc, o_up);
+            if (gvp) store_vec<T>(gvp + rc, o_vp);
+        }
+        um = uc; uc = un; vm = vc; vc = vn; am = ac; ac = an; bm = bc; bc = bn; dm = dc; dc = dn;
+    }
+}
+
+template <typename T, int STENCIL>
+__global__ __launch_bounds__(256) void fd_residual_bwd_generic_kernel(const T* __restrict__ u, const T* __restrict__ v,
+                                                                       const T* __restrict__ ga, const T* __restrict__ gb, const T* __restrict__ gd,
+                                                                       T* __restrict__ gu, T* __restrict__ gv, T* __restrict__ gp,
+                                                                       T* __restrict__ gup, T* __restrict__ gvp, int nx, int ny, ResK<T> k) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= ny) return;
+    const size_t g = (size_t)blockIdx.z * nx * ny;
+    const int im = i == 0 ? nx - 1 : i - 1, in = i + 1 == nx ? 0 : i + 1;
+    const int jm = j == 0 ? ny - 1 : j - 1, jn = j + 1 == ny ? 0 : j + 1;
+    auto at = [&](const T* f, int a, int b) { return f[g + (size_t)a * ny + b]; };
+    const T a = at(ga, i, j), bb = at(gb, i, j);
+    const T ux = (at(u, in, j) - at(u, im, j)) * k.inv_2dx, uy = (at(u, i, jn) - at(u, i, jm)) * k.inv_2dy;
+    const T vx = (at(v, in, j) - at(v, im, j)) * k.inv_2dx, vy = (at(v, i, jn) - at(v, i, jm)) * k.inv_2dy;
+    const T dx_aud = ((at(ga, in, j) * at(u, in, j) + at(gd, in, j)) - (at(ga, im, j) * at(u, im, j) + at(gd, im, j))) * k.inv_2dx;
+    const T dy_av = (at(ga, i, jn) * at(v, i, jn) - at(ga, i, jm) * at(v, i, jm)) * k.inv_2dy;
+    const T dx_bu = (at(gb, in, j) * at(u, in, j) - at(gb, im, j) * at(u, im, j)) * k.inv_2dx;
+    const T dy_bvd = ((at(gb, i, jn) * at(v, i, jn) + at(gd, i, jn)) - (at(gb, i, jm) * at(v, i, jm) + at(gd, i, jm))) * k.inv_2dy;
+    const T dx_a = (at(ga, in, j) - at(ga, im, j)) * k.inv_2dx, dy_b = (at(gb, i, jn) - at(gb, i, jm)) * k.inv_2dy;
+    auto lap = [&](const T* f, T c) {
+        double l = ((double)at(f, in, j) - 2.0 * c + (double)at(f, im, j)) * k.inv_dx2 + ((double)at(f, i, jn) - 2.0 * c + (double)at(f, i, jm)) * k.inv_dy2;
+        if constexpr (STENCIL == 9)
+            l += k.c9 * (((double)at(f, im, jm) + at(f, im, jn) + at(f, in, jm) + at(f, in, jn))
+                         - 2.0 * ((double)at(f, im, j) + at(f, in, j) + at(f, i, jm) + at(f, i, jn)) + 4.0 * c);
+        return l;
+    };
+    const size_t c = g + (size_t)i * ny + j;
+    gu[c] = a * k.inv_dt + a * ux + bb * vx - dx_aud - dy_av - k.nu * (T)lap(ga, a);
+    gv[c] = bb * k.inv_dt + a * uy + bb * vy - dx_bu - dy_bvd - k.nu * (T)lap(gb, bb);
+    gp[c] = -(dx_a + dy_b) * k.inv_rho;
+    if (gup) gup[c] = -a * k.inv_dt;
+    if (gvp) gvp[c] = -bb * k.inv_dt;
+}
+
+template <typename T>
+int fd_residual_bwd(const T* u, const T* v, const T* ga, const T* gb, const T* gd, T* gu, T* gv, T* gp, T* gup, T* gvp,
+                    int batch, int nx, int ny, double dt, double dx, double dy, double rho, double nu, int stencil, hipStream_t s) {
+    if (!u || !v || !ga || !gb || !gd || !gu || !gv || !gp || !field_args_ok(batch, nx, ny))
+        return fail(NNS_ERR_INVALID_ARG, "fd_residual_bwd: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
+    if (stencil != 5 && stencil != 9) return fail(NNS_ERR_INVALID_ARG, "fd_residual_bwd: stencil must be 5 or 9 (got %d)", stencil);
+    if (dt == 0 || dx == 0 || dy == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "fd_residual_bwd: dt, dx, dy, rho must be non-zero");
+    const ResK<T> k = make_resk<T>(dt, dx, dy, rho, nu);
+    constexpr int V = VecT<T>::V;
+    uintptr_t bits = 0;
+    for (const void* q : {(const void*)u, (const void*)v, (const void*)ga, (const void*)gb, (const void*)gd, (const void*)gu, (const void*)gv, (const void*)gp, (const void*)gup, (const void*)gvp})
+        bits |= reinterpret_cast<uintptr_t>(q);
+    if (ny % V == 0 && ny >= 2 * V && (bits & 15) == 0) {
+        const int nvec = ny / V, nstrips = (nvec + 255) / 256;
+        long want = 2048;
+        int R = (int)(((long)batch * nx * nstrips + want - 1) / want);
+        R = R < 4 ? 4 : (R > NNS_FD_RMAX ? NNS_FD_RMAX : R);
+        const int nbands = (nx + R - 1) / R;
+        const long nblocks = (long)batch * nbands * nstrips;
+        if (nblocks > 0x7fffffffL) return fail(NNS_ERR_UNSUPPORTED, "fd_residual_bwd: grid too large");
+        if (stencil == 5)
+            hipLaunchKernelGGL((fd_residual_bwd_vec_kernel<T, 5>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, ga, gb, gd, gu, gv, gp, gup, gvp, nx, ny, R, nbands, nstrips, k);
+        else
+            hipLaunchKernelGGL((fd_residual_bwd_vec_kernel<T, 9>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, ga, gb, gd, gu, gv, gp, gup, gvp, nx, ny, R, nbands, nstrips, k);
+    } else {
+        const dim3 grid((ny + 255) / 256, nx, batch);
+        if (stencil == 5)
+            hipLaunchKernelGGL((fd_residual_bwd_generic_kernel<T, 5>), grid, dim3(256), 0, s, u, v, ga, gb, gd, gu, gv, gp, gup, gvp, nx, ny, k);
+        else
+            hipLaunchKernelGGL((fd_residual_bwd_generic_kernel<T, 9>), grid, dim3(256), 0, s, u, v, ga, gb, gd, gu, gv, gp, gup, gvp, nx, ny, k);
+    }
+    return check_launch("fd_residual_bwd");
+}
+
 }  // namespace
 
 NNS_API int nns_fd_residual_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
@@ -237,4 +399,15 @@ NNS_API int nns_fd_residual_f64(const double* u, const double* v, const double* 
                                 double* r_u, double* r_v, double* r_div, int batch, int nx, int ny, double dt, double dx, double dy,
                                 double rho, double nu, int stencil, void* stream) {
     return fd_residual<double>(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream));
+}
+
+NNS_API int nns_fd_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,
+                                    float* grad_u, float* grad_v, float* grad_p, float* grad_u_prev, float* grad_v_prev,
+                                    int batch, int nx, int ny, double dt, double dx, double dy, double rho, double nu, int stencil, void* stream) {
+    return fd_residual_bwd<float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_residual_bwd_f64(const double* u, const double* v, const double* g_u, const double* g_v, const double* g_div,
+                                    double* grad_u, double* grad_v, double* grad_p, double* grad_u_prev, double* grad_v_prev,
+                                    int batch, int nx, int ny, double dt, double dx, double dy, double rho, double nu, int stencil, void* stream) {
+    return fd_residual_bwd<double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream));
 }

@@ -40,6 +40,7 @@ _DUAL = {
     'nns_fd_jacobi': [_P] * 3 + [_I] * 3 + [_D] * 2 + [_I, _BCP, _P],
     'nns_fd_direct_update': [_P] * 5 + [_I] * 3 + [_D] * 5 + [_P],
     'nns_fd_residual': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
+    'nns_fd_residual_bwd': [_P] * 10 + [_I] * 3 + [_D] * 5 + [_I, _P],
 }
 _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],

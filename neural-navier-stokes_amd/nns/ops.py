@@ -156,6 +156,37 @@ def fd_residual(u, v, p, u_prev, v_prev, dt, dx, dy, rho, nu, stencil=5, out=Non
     return ru, rv, rd
 
 
+def fd_residual_bwd(u, v, g_u, g_v, g_div, dt, dx, dy, rho, nu, stencil=5, want_prev=True):
+    """Vector-Jacobian product of fd_residual: returns (grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev)
+    (the last two None unless want_prev)."""
+    suf, (B, nx, ny) = _chk(u, v, g_u, g_v, g_div)
+    gu, gv, gp = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    gup, gvp = (torch.empty_like(u), torch.empty_like(u)) if want_prev else (None, None)
+    _call('nns_fd_residual_bwd', suf, _p(u), _p(v), _p(g_u), _p(g_v), _p(g_div), _p(gu), _p(gv), _p(gp),
+          _p(gup) if want_prev else None, _p(gvp) if want_prev else None, B, nx, ny, dt, dx, dy, rho, nu, int(stencil), _stream())
+    return gu, gv, gp, gup, gvp
+
+
+class FdResidualFn(torch.autograd.Function):
+    """fd_residual as an autograd node (forward: nns_fd_residual, backward: nns_fd_residual_bwd, the adjoint stencils)."""
+
+    @staticmethod
+    def forward(ctx, u, v, p, u_prev, v_prev, dt, dx, dy, rho, nu, stencil):
+        u, v, p, u_prev, v_prev = (t.contiguous() for t in (u, v, p, u_prev, v_prev))
+        ctx.save_for_backward(u, v)
+        ctx.consts = (dt, dx, dy, rho, nu, stencil)
+        return fd_residual(u, v, p, u_prev, v_prev, dt, dx, dy, rho, nu, stencil)
+
+    @staticmethod
+    def backward(ctx, g_u, g_v, g_d):
+        u, v = ctx.saved_tensors
+        dt, dx, dy, rho, nu, stencil = ctx.consts
+        zero = lambda g: torch.zeros_like(u) if g is None else g.contiguous()
+        want_prev = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        gu, gv, gp, gup, gvp = fd_residual_bwd(u, v, zero(g_u), zero(g_v), zero(g_d), dt, dx, dy, rho, nu, stencil, want_prev)
+        return (gu, gv, gp, gup, gvp) + (None,) * 6
+
+
 def spec_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, out=None):
     suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
     if suf != '_f32':

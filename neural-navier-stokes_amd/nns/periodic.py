@@ -36,6 +36,19 @@ class ResidualEngine(object):
             return self.spectral(u, v, p, u_prev, v_prev, out)
         return self.fd(u, v, p, u_prev, v_prev, 5 if self.backend == 'fd5' else 9, out)
 
+    def differentiable(self, u, v, p, u_prev, v_prev):
+        """The residual as an autograd node (inputs may require grad): forward and backward are both HIP kernels
+        (the backward applies the adjoint operators, see oracle/periodic.py: residual_vjp)."""
+        if self.backend == 'spectral':
+            raise NotImplementedError("differentiable spectral residual: not built yet (FD back-ends only)")
+        return ops.FdResidualFn.apply(u, v, p, u_prev, v_prev, self.dt, self.dx, self.dy, self.rho, self.nu, 5 if self.backend == 'fd5' else 9)
+
+    def physics_loss(self, u, v, p, u_prev, v_prev, w_div=1.0):
+        """Mean-square momentum + divergence residual: the physics-informed loss term of SURVEY.md section 8 (f) rank 2
+        (hypothesis: src/neural_spectral/derivations/derivation.tex:25-34)."""
+        r_u, r_v, r_d = self.differentiable(u, v, p, u_prev, v_prev)
+        return (r_u * r_u).mean() + (r_v * r_v).mean() + w_div * (r_d * r_d).mean()
+
     def both(self, u, v, p, u_prev, v_prev, out_fd=None, out_spec=None, stencil=5):
         """The 'stencil + spectral residual' of BASELINE.json: both back-ends on the same inputs."""
         return (self.fd(u, v, p, u_prev, v_prev, stencil, out_fd), self.spectral(u, v, p, u_prev, v_prev, out_spec))

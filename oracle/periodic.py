@@ -87,6 +87,45 @@ def spectral_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu):
     return r_u, r_v, ux + vy
 
 
+def residual_vjp(u, v, g_u, g_v, g_div, dt, rho, nu, derivs):
+    """Vector-Jacobian product of the residual (either back-end): given g_* = dLoss/dr_*, returns
+    (dLoss/du, dLoss/dv, dLoss/dp, dLoss/du_prev, dLoss/dv_prev).  `derivs(f) -> (f_x, f_y, lap f)` is the
+    back-end's linear operator triple.  Both back-ends have antisymmetric first derivatives (periodic central
+    difference; i k with the Nyquist mode dropped) and a symmetric Laplacian, so D^T = -D, L^T = L:
+
+      grad_u = g_u/dt + g_u u_x + g_v v_x - D_x(g_u u) - D_y(g_u v) - nu L g_u - D_x g_div
+      grad_v = g_v/dt + g_u u_y + g_v v_y - D_x(g_v u) - D_y(g_v v) - nu L g_v - D_y g_div
+      grad_p = -(D_x g_u + D_y g_v)/rho,   grad_u_prev = -g_u/dt,   grad_v_prev = -g_v/dt
+
+    (p enters the residual linearly, so the product does not depend on it).  Pinned by the directional-derivative
+    identity <J d, g> = <d, J^T g> in tests/test_oracle_periodic.py -- the residual is quadratic, so a central
+    difference gives J d exactly."""
+    ux, uy, _ = derivs(u)
+    vx, vy, _ = derivs(v)
+    aux, _, _ = derivs(g_u * u)
+    _, avy, _ = derivs(g_u * v)
+    bux, _, _ = derivs(g_v * u)
+    _, bvy, _ = derivs(g_v * v)
+    ax, _, la = derivs(g_u)
+    _, by, lb = derivs(g_v)
+    dx_, dy_, _ = derivs(g_div)
+    grad_u = g_u / dt + g_u * ux + g_v * vx - aux - avy - nu * la - dx_
+    grad_v = g_v / dt + g_u * uy + g_v * vy - bux - bvy - nu * lb - dy_
+    grad_p = -(ax + by) / rho
+    return grad_u, grad_v, grad_p, -g_u / dt, -g_v / dt
+
+
+def fd_residual_vjp(u, v, g_u, g_v, g_div, dt, dx, dy, rho, nu, stencil=5):
+    """VJP of fd_residual.  The pressure gradient always uses the 5-point first derivatives (as fd_residual does);
+    first derivatives do not depend on `stencil`, so one operator triple serves all terms."""
+    return residual_vjp(u, v, g_u, g_v, g_div, dt, rho, nu, lambda f: fd_derivs(f, dx, dy, stencil))
+
+
+def spectral_residual_vjp(u, v, g_u, g_v, g_div, dt, Lx, Ly, rho, nu):
+    """VJP of spectral_residual."""
+    return residual_vjp(u, v, g_u, g_v, g_div, dt, rho, nu, lambda f: spectral_derivs(f, Lx, Ly))
+
+
 def taylor_green(nx, ny, t, nu, rho=1.0, Lx=2 * np.pi, Ly=2 * np.pi):
     """Analytic decaying Taylor-Green vortex on [0,Lx)x[0,Ly) (exact NS solution for
     Lx = Ly = 2*pi): u = cos x sin y F, v = -sin x cos y F, p = -rho/4 (cos 2x + cos 2y) F^2,

@@ -81,3 +81,28 @@ def test_batched_leading_axes_and_non_square():
     gx, gy, gl = OP.fd_derivs(f, 0.1, 0.2, 9)
     a, b, c = OP.fd_derivs(f[2, 0], 0.1, 0.2, 9)
     np.testing.assert_array_equal(gl[2, 0], c)
+
+
+def test_residual_vjp_is_the_adjoint_of_the_jacobian():
+    """<J d, g> = <d, J^T g> for both back-ends and both stencils.  The residual is quadratic in (u, v) and linear in
+    the rest, so J d = (r(w + d) - r(w - d)) / 2 exactly (no step-size error)."""
+    rng = np.random.default_rng(5)
+    nx, ny = 16, 12
+    Lx, Ly, dt, rho, nu = 2.0, 3.0, 0.01, 1.3, 0.05
+    dx, dy = Lx / nx, Ly / ny
+    w = [rng.standard_normal((2, nx, ny)) for _ in range(5)]          # u, v, p, u_prev, v_prev
+    d = [rng.standard_normal((2, nx, ny)) for _ in range(5)]
+    g = [rng.standard_normal((2, nx, ny)) for _ in range(3)]
+    cases = [
+        (lambda *a: OP.fd_residual(*a, dt, dx, dy, rho, nu, 5), lambda *a: OP.fd_residual_vjp(*a, dt, dx, dy, rho, nu, 5)),
+        (lambda *a: OP.fd_residual(*a, dt, dx, dy, rho, nu, 9), lambda *a: OP.fd_residual_vjp(*a, dt, dx, dy, rho, nu, 9)),
+        (lambda *a: OP.spectral_residual(*a, dt, Lx, Ly, rho, nu), lambda *a: OP.spectral_residual_vjp(*a, dt, Lx, Ly, rho, nu)),
+    ]
+    for res, vjp in cases:
+        rp = res(*[a + b for a, b in zip(w, d)])
+        rm = res(*[a - b for a, b in zip(w, d)])
+        Jd = [(a - b) / 2 for a, b in zip(rp, rm)]
+        lhs = sum(float((a * b).sum()) for a, b in zip(Jd, g))
+        grads = vjp(w[0], w[1], *g)
+        rhs = sum(float((a * b).sum()) for a, b in zip(grads, d))
+        assert abs(lhs - rhs) <= 1e-10 * max(1.0, abs(lhs)), (lhs, rhs)
