@@ -421,6 +421,39 @@ def spec_derivs(f, Lx, Ly, want=('x', 'y', 'lap'), precise=True):
     return out
 
 
+def spec_residual_bwd(u, v, g_u, g_v, g_div, dt, Lx, Ly, rho, nu, precise=True, want_prev=True):
+    """Vector-Jacobian product of spec_residual (oracle/periodic.py: spectral_residual_vjp).  First version: the adjoint
+    operators (D^T = -D, L^T = L) are applied by the HIP spectral-derivative kernel (nns_spec_derivs_f32, 8 launches)
+    and combined with elementwise tensor ops; a fused two-pass kernel like the forward's is the planned replacement."""
+    _f32(u, v, g_u, g_v, g_div)
+    d = lambda f, *want: spec_derivs(f.contiguous(), Lx, Ly, want, precise)
+    du, dv = d(u, 'x', 'y'), d(v, 'x', 'y')
+    da, db = d(g_u, 'x', 'lap'), d(g_v, 'y', 'lap')
+    grad_u = g_u / dt + g_u * du['x'] + g_v * dv['x'] - d(g_u * u + g_div, 'x')['x'] - d(g_u * v, 'y')['y'] - nu * da['lap']
+    grad_v = g_v / dt + g_u * du['y'] + g_v * dv['y'] - d(g_v * u, 'x')['x'] - d(g_v * v + g_div, 'y')['y'] - nu * db['lap']
+    grad_p = -(da['x'] + db['y']) / rho
+    return grad_u, grad_v, grad_p, (-g_u / dt if want_prev else None), (-g_v / dt if want_prev else None)
+
+
+class SpecResidualFn(torch.autograd.Function):
+    """spec_residual as an autograd node."""
+
+    @staticmethod
+    def forward(ctx, u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise):
+        u, v, p, u_prev, v_prev = (t.contiguous() for t in (u, v, p, u_prev, v_prev))
+        ctx.save_for_backward(u, v)
+        ctx.consts = (dt, Lx, Ly, rho, nu, precise)
+        return spec_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise)
+
+    @staticmethod
+    def backward(ctx, g_u, g_v, g_d):
+        u, v = ctx.saved_tensors
+        dt, Lx, Ly, rho, nu, precise = ctx.consts
+        zero = lambda g: torch.zeros_like(u) if g is None else g.contiguous()
+        want_prev = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        return spec_residual_bwd(u, v, zero(g_u), zero(g_v), zero(g_d), dt, Lx, Ly, rho, nu, precise, want_prev) + (None,) * 6
+
+
 def spec_rfft2(f):
     """numpy.fft.rfft2 of float32 [B, nx, ny] -> complex64 [B, nx, ny//2+1]."""
     _f32(f)

@@ -40,7 +40,7 @@ class ResidualEngine(object):
         """The residual as an autograd node (inputs may require grad): forward and backward are both HIP kernels
         (the backward applies the adjoint operators, see oracle/periodic.py: residual_vjp)."""
         if self.backend == 'spectral':
-            raise NotImplementedError("differentiable spectral residual: not built yet (FD back-ends only)")
+            return ops.SpecResidualFn.apply(u, v, p, u_prev, v_prev, self.dt, self.Lx, self.Ly, self.rho, self.nu, self.precise)
         return ops.FdResidualFn.apply(u, v, p, u_prev, v_prev, self.dt, self.dx, self.dy, self.rho, self.nu, 5 if self.backend == 'fd5' else 9)
 
     def physics_loss(self, u, v, p, u_prev, v_prev, w_div=1.0):
