@@ -91,6 +91,16 @@ def cfg3():
     ws, bs = [w.detach() for w in mlp.weights], [b.detach() for b in mlp.biases]
     tb = timeit(lambda: ops.pixel_mlp_bwd(x, gy, ws, bs), iters=10)
     out['pixel_mlp_d8_w64_bf16_backward'] = dict(ms=1e3 * tb, Gpix_s=16 * n * n / tb / 1e9, TFLOPs=3 * flops / tb / 1e12)
+    # the physics-informed training step (data loss + residual of the prediction), Adam included
+    from nns.neural_spectral.physics_informed import FieldStepper, train_step
+    state = torch.as_tensor(np.stack([np.tile(a, (4, 1, 1)) for a in residual_inputs(4, n)[3:] + residual_inputs(4, n)[2:3]], axis=1), device='cuda')
+    target = torch.as_tensor(np.stack([np.tile(a, (4, 1, 1)) for a in residual_inputs(4, n)[:3]], axis=1), device='cuda')
+    for backend in ('fd9', 'spectral'):
+        stepper = FieldStepper(8, 64).cuda()
+        opt = torch.optim.Adam(stepper.parameters(), lr=1e-4)
+        e2 = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
+        ts = timeit(lambda: train_step(stepper, e2, opt, state, target, lam=0.1), iters=10)
+        out['physics_informed_step_d8_w64_bf16_%s' % backend] = dict(ms=1e3 * ts, Mpix_s=16 * n * n / ts / 1e6)
     return dict(config='cfg3 512x512 Re=1000: residual (FD5 + spectral, batch 64) + depth-8 width-64 pixel MLP',
                 residual_updates_per_s=B * n * n / tr, **out)
 
