@@ -71,26 +71,88 @@ __device__ void stage_weights(const PixelMlpDesc& d, const float* __restrict__ W
     }
 }
 
+// Forward launch geometry: kFwdThreads / 64 waves share one LDS copy of the weights.  With 50-60 KB of fragments
+// (depth 8, width 64, bf16) two workgroups fit a CU, so 6 waves per workgroup give 3 waves per SIMD (<= 170 VGPRs)
+// instead of 2; the next tile's input pixels are loaded while the current tile runs through the layers.
+#ifndef NNS_PM_THREADS
+#define NNS_PM_THREADS 256
+#endif
+constexpr int kFwdThreads = NNS_PM_THREADS, kFwdWaves = kFwdThreads / 64;
+
+constexpr int kGenThreads = 256, kGenWaves = 4;      // the runtime-shaped (float32) kernel
+
 template <bool BF16>
-__global__ __launch_bounds__(256) void pixel_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
-                                                             float* __restrict__ y, long npix_total, int P, PixelMlpDesc d) {
+__global__ __launch_bounds__(kGenThreads) void pixel_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                     float* __restrict__ y, long npix_total, int P, PixelMlpDesc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    stage_weights<BF16>(d, W, Bv, lds, threadIdx.x, 256);
+    stage_weights<BF16>(d, W, Bv, lds, threadIdx.x, kGenThreads);
     __syncthreads();
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
     const int cin0 = d.cin[0], coutL = d.cout[d.nlayers - 1];
     const long ntiles = (npix_total + 31) / 32;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long tstride = (long)gridDim.x * kGenWaves;
+    // input tile: up to 64 channels x 32 pixels = two 32-row accumulator tiles; `nxt` is the prefetched next tile
+    auto load_tile = [&](long tile, f32x16 (&a)[2]) {
         const long gp = tile * 32 + r;
-        const bool ok = gp < npix_total;
+        const bool ok = tile < ntiles && gp < npix_total;
         const long b = ok ? gp / P : 0, p = ok ? gp % P : 0;
         const float* xb = x + (size_t)b * cin0 * P + p;
-        // activations: up to 64 channels x 32 pixels = two 32-row accumulator tiles
-        f32x16 act[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); act[t][i] = (ok && c < cin0) ? xb[(size_t)c * P] : 0.f; }
+            for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); a[t][i] = (ok && c < cin0) ? xb[(size_t)c * P] : 0.f; }
+    };
+    f32x16 nxt[2];
+    long tile = (long)blockIdx.x * kGenWaves + wave;
+    load_tile(tile, nxt);
+    for (; tile < ntiles; tile += tstride) {
+        const long gp = tile * 32 + r;
+        const bool ok = gp < npix_total;
+        const long b = ok ? gp / P : 0, p = ok ? gp % P : 0;
+        f32x16 act[2];
+        act[0] = nxt[0]; act[1] = nxt[1];
+        load_tile(tile + tstride, nxt);
+        if constexpr (BF16) {
+            // The loop-carried state is the PACKED bf16 operand fragments, not float32 activations: after a layer's MFMAs
+            // the accumulators are converted pairwise (v_cvt_pk_bf16_f32) and ReLU is a packed integer max with 0
+            // (bf16 is sign-magnitude: max as int16 with 0 zeroes exactly the negative values) -- 32 VALU per layer
+            // instead of ~150 (the kernel was VALU-bound: 1600 VALU per tile for 54 MFMAs).
+            bf16x8 fr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fr[s][j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
+            const int nl = d.nlayers;
+            for (int l = 0; l < nl; ++l) {
+                const int cin = d.cin[l], cout = d.cout[l];
+                const int ots = (cout + 31) / 32, ss = (cin + 15) / 16;
+                const float* bl = reinterpret_cast<const float*>(lds + d.lds_bias[l]);
+                const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds + d.lds_off[l]);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    if (ot < ots) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) act[ot][i] = bl[32 * ot + acc_row(i, h)];       // bias (0 in the padding rows)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (s < ss) act[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ot * ss + s) * 64 + lane], fr[s], act[ot], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) act[ot][i] = 0.f;
+                    }
+                }
+                if (l + 1 < nl) {
+                    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        bf16x8 t;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
+                        fr[s] = __builtin_elementwise_max(t, zero);
+                    }
+                }
+            }
+        } else {
         for (int l = 0; l < d.nlayers; ++l) {
             const int cin = d.cin[l], cout = d.cout[l];
             const int ots = (cout + 31) / 32;
@@ -101,28 +163,14 @@ __global__ __launch_bounds__(256) void pixel_mlp_fwd_kernel(const float* __restr
                 if (ot < ots) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) out[ot][i] = bl[32 * ot + acc_row(i, h)];          // bias as the initial accumulator
-                    if constexpr (BF16) {
-                        const int ss = (cin + 15) / 16;
-                        const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds + d.lds_off[l]);
+                    const int kbs = (cin + 31) / 32;
+                    const float* wl = reinterpret_cast<const float*>(lds + d.lds_off[l]);
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            if (s < ss) {
-                                bf16x8 bfrag;
+                    for (int kb = 0; kb < 2; ++kb) {
+                        if (kb < kbs) {
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) bfrag[j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
-                                out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ot * ss + s) * 64 + lane], bfrag, out[ot], 0, 0, 0);
-                            }
-                        }
-                    } else {
-                        const int kbs = (cin + 31) / 32;
-                        const float* wl = reinterpret_cast<const float*>(lds + d.lds_off[l]);
-#pragma unroll
-                        for (int kb = 0; kb < 2; ++kb) {
-                            if (kb < kbs) {
-#pragma unroll
-                                for (int i = 0; i < 16; ++i)
-                                    out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[((ot * kbs + kb) * 16 + i) * 64 + lane], act[kb][i], out[ot], 0, 0, 0);
-                            }
+                            for (int i = 0; i < 16; ++i)
+                                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[((ot * kbs + kb) * 16 + i) * 64 + lane], act[kb][i], out[ot], 0, 0, 0);
                         }
                     }
                 } else {
@@ -136,6 +184,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_fwd_kernel(const float* __restr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) act[t][i] = relu ? fmaxf(out[t][i], 0.f) : out[t][i];
         }
+        }
         if (ok) {
             float* yb = y + (size_t)b * coutL * P + p;
 #pragma unroll
@@ -146,6 +195,181 @@ __global__ __launch_bounds__(256) void pixel_mlp_fwd_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 forward, UNIFORM layer shape.  Every layer is padded (with zero weights) to the same square shape
+// 32 OT x 32 OT (OT = 1: widths <= 32, OT = 2: widths <= 64), so the layer body has no data-dependent branch: all
+// 2 OT^2 weight fragments of a layer are fetched from LDS up front and its 2 OT^2 MFMAs issue back to back, the
+// accumulators are converted pairwise to the next layer's operand fragments (v_cvt_pk_bf16_f32) and ReLU is a packed
+// integer max with 0 (bf16 is sign-magnitude).  (The runtime-shaped kernel above put an `if` and a full
+// `s_waitcnt lgkmcnt(0)` in front of every MFMA: 12 % MFMA utilisation.)  Padding costs 64 instead of 54 MFMAs per
+// tile at depth 8 / width 64 / 3 in / 3 out.
+// LDS image: [layer][ot][s][lane 64][8] bf16 fragments, then [layer][32 OT] float biases.
+template <int OT>
+struct UniLds {
+    static constexpr int SS = 2 * OT;
+    static constexpr int W_BYTES = OT * SS * 64 * 16;            // fragments of one layer
+    static constexpr int B_BYTES = OT * 32 * 4;
+    __host__ __device__ static int total(int nlayers) { return nlayers * (W_BYTES + B_BYTES); }
+};
+
+// Staging walks the REAL [out][in] matrices with consecutive threads on consecutive input channels (coalesced reads, no
+// div/mod per element) and scatters into the zero-filled fragment image.  (Walking the image and gathering from global
+// memory instead cost ~100 us per workgroup -- more than the whole tile loop at depth 8 / width 64.)
+template <int OT>
+__device__ void stage_uniform(const PixelMlpDesc& d, const float* __restrict__ W, const float* __restrict__ B, unsigned char* lds, int tid, int nthreads) {
+    using U = UniLds<OT>;
+    constexpr int SS = U::SS;
+    const int total = U::total(d.nlayers);
+    for (int e = tid; e < total / 16; e += nthreads) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    for (int l = 0; l < d.nlayers; ++l) {
+        const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
+        const float* Wl = W + d.woff[l];
+        unsigned short* dst = reinterpret_cast<unsigned short*>(lds + l * U::W_BYTES);
+        int row = tid / cin, k = tid - row * cin;                 // one division per thread and layer, then incremental
+        const int drow = nthreads / cin, dk = nthreads - drow * cin;
+        for (int e = tid; e < n; e += nthreads) {
+            const int ot = row >> 5, r = row & 31, s2 = k >> 4, kk = k & 15;
+            const int lane = r + 32 * ((kk >> 2) & 1), j = 4 * (kk >> 3) + (kk & 3);
+            dst[(((ot * SS + s2) * 64 + lane) << 3) + j] = f2bf(Wl[e]);
+            row += drow; k += dk;
+            if (k >= cin) { k -= cin; ++row; }
+        }
+        float* bl = reinterpret_cast<float*>(lds + d.nlayers * U::W_BYTES + l * U::B_BYTES);
+        for (int e = tid; e < cout; e += nthreads) bl[e] = B[d.boff[l] + e];
+    }
+}
+
+// Tile I/O without per-site branches.  Fragment element (s, j) of lane half h holds channel 16 s + 8 (j>>2) + 4 h + (j&3)
+// and accumulator register i of tile t holds channel 32 t + (i&3) + 8 (i>>2) + 4 h: both increase with the site index,
+// so the sites are visited in channel order and the walk stops (uniformly) at the first site beyond the channel count --
+// 3 channels touch 3 sites, not 64.  Loads are unconditional (pixel and channel clamped into range) and zeroed by a
+// select; stores are masked per lane.
+template <int SS>
+__device__ __forceinline__ void load_frags(const float* __restrict__ xb, size_t P, int cin0, bool ok, int h, bf16x8 (&f)[SS]) {
+#pragma unroll
+    for (int s = 0; s < SS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[s][j] = 0;
+#pragma unroll
+    for (int s = 0; s < SS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cmin = 16 * s + 8 * (j >> 2) + (j & 3);
+            if (cmin >= cin0) return;
+            const int c = cmin + 4 * h;
+            const float v = xb[(size_t)(c < cin0 ? c : cin0 - 1) * P];
+            f[s][j] = (short)f2bf((ok && c < cin0) ? v : 0.f);
+        }
+}
+
+template <int OT>
+__device__ __forceinline__ void store_acc(float* __restrict__ yb, size_t P, int cout, int h, const f32x16 (&a)[OT]) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rmin = 32 * t + (i & 3) + 8 * (i >> 2);
+            if (rmin >= cout) return;
+            const int c = rmin + 4 * h;
+            if (c < cout) yb[(size_t)c * P] = a[t][i];
+        }
+}
+
+// PT = 2 pixel tiles (64 pixels) per wave and pass: every weight fragment read from LDS feeds two MFMAs and the bias
+// is read once for both tiles.  With one tile per pass the kernel is LDS-bandwidth-bound: a 64x64 layer re-reads 8 KB of
+// fragments + 8 KB of bias per 256 MFMA cycles of ONE SIMD, i.e. the CU's whole 128 B/clk, twice over.
+constexpr int kPT = 2;
+
+template <int OT>
+__global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void pixel_mlp_fwd_uniform_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                             float* __restrict__ y, long npix_total, int P, PixelMlpDesc d) {
+    using U = UniLds<OT>;
+    constexpr int SS = U::SS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    stage_uniform<OT>(d, W, Bv, lds, threadIdx.x, kFwdThreads);
+    __syncthreads();
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
+    const int nl = d.nlayers, cin0 = d.cin[0], coutL = d.cout[nl - 1];
+    const long ngroups = (npix_total + 32 * kPT - 1) / (32 * kPT);
+    const long gstride = (long)gridDim.x * kFwdWaves;
+    const unsigned char* bias0 = lds + nl * U::W_BYTES;
+    // input pixels of group g as bf16 operand fragments (zero beyond cin0 / the last pixel)
+    auto load_group = [&](long g, bf16x8 (&f)[kPT][SS]) {
+#pragma unroll
+        for (int pt = 0; pt < kPT; ++pt) {
+            const long gp = (g * kPT + pt) * 32 + r;
+            const bool ok = g < ngroups && gp < npix_total;
+            const long gc = ok ? gp : npix_total - 1;                       // clamped: the load itself is unconditional
+            load_frags<SS>(x + (size_t)(gc / P) * cin0 * P + gc % P, (size_t)P, cin0, ok, h, f[pt]);
+        }
+    };
+    for (long g = (long)blockIdx.x * kFwdWaves + wave; g < ngroups; g += gstride) {
+        bf16x8 fr[kPT][SS];
+        load_group(g, fr);                 // no register prefetch of the next group: the 32 VGPRs buy the second wave per SIMD
+        // Layer loop, software-pipelined by hand: fragment n+1 is requested before the kPT MFMAs of fragment n (the
+        // compiler alone serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma: ~17 k wait cycles per 64 pixels), the
+        // NEXT layer's first fragment and bias are requested before this layer's conversion phase, and the bias goes
+        // straight into the first MFMA of each chain as its accumulator input.
+        f32x16 acc[kPT][OT], bn[OT];
+        const bf16x8* wl0 = reinterpret_cast<const bf16x8*>(lds) + lane;
+        auto fetch_bias = [&](int l) {
+            const float* bl = reinterpret_cast<const float*>(bias0 + l * U::B_BYTES);
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bn[ot][i] = bl[32 * ot + acc_row(i, h)];
+        };
+        fetch_bias(0);
+        bf16x8 w = wl0[0];
+        for (int l = 0; l < nl; ++l) {
+            const bf16x8* wl = wl0 + (size_t)l * (U::W_BYTES / 16);
+            const int ln = l + 1 < nl ? l + 1 : l;
+#pragma unroll
+            for (int idx = 0; idx < OT * SS; ++idx) {
+                const int ot = idx / SS, s2 = idx % SS;
+                const bf16x8 wn = idx + 1 < OT * SS ? wl[(idx + 1) * 64] : wl0[(size_t)ln * (U::W_BYTES / 16)];
+#pragma unroll
+                for (int pt = 0; pt < kPT; ++pt)
+                    acc[pt][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fr[pt][s2], s2 == 0 ? bn[ot] : acc[pt][ot], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one LDS read (fragment n+1) ...
+                __builtin_amdgcn_sched_group_barrier(0x008, kPT, 0);      // ... ahead of the MFMAs of fragment n
+                w = wn;
+            }
+            if (l + 1 < nl) {
+                fetch_bias(l + 1);
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int pt = 0; pt < kPT; ++pt)
+#pragma unroll
+                    for (int s = 0; s < SS; ++s) {
+                        bf16x8 t;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(acc[pt][s >> 1][8 * (s & 1) + j]);
+                        fr[pt][s] = __builtin_elementwise_max(t, zero);
+                    }
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < kPT; ++pt) {
+            const long gp = (g * kPT + pt) * 32 + r;
+            if (gp < npix_total) store_acc<OT>(y + (size_t)(gp / P) * coutL * P + gp % P, (size_t)P, coutL, h, acc[pt]);
+        }
+    }
+}
+
+template <int OT>
+int launch_fwd_uniform(const float* x, const float* weights, const float* biases, float* y, long npix, int P, const PixelMlpDesc& d, hipStream_t s) {
+    const int lds = UniLds<OT>::total(d.nlayers);
+    if (lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_fwd: weights need %d B of LDS (> 160 KiB)", lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_uniform_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const long ngroups = (npix + 32 * kPT - 1) / (32 * kPT);
+    // persistent: one generation of workgroups (2 per CU fit by LDS), so the weights are staged once per workgroup
+    long blocks = (ngroups + kFwdWaves - 1) / kFwdWaves; if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(pixel_mlp_fwd_uniform_kernel<OT>, dim3((unsigned)blocks), dim3(kFwdThreads), lds, s, x, weights, biases, y, npix, P, d);
+    return check_launch("pixel_mlp_fwd");
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward (bfloat16 operands, float32 accumulation).  One launch computes, for the same stack,
@@ -438,20 +662,20 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
         d.lds_bias[l] = lds;
         lds += ots * 32 * 4;
     }
-    if (lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_fwd: weights need %d B of LDS (> 160 KiB)", lds);
+    if (!bf16 && lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_fwd: weights need %d B of LDS (> 160 KiB)", lds);
     const long npix = (long)mb * P;
     const long ntiles = (npix + 31) / 32;
-    long blocks = (ntiles + 3) / 4; if (blocks > 1024) blocks = 1024;
+    long blocks = (ntiles + kGenWaves - 1) / kGenWaves; if (blocks > 1024) blocks = 1024;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
     if (bf16) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(pixel_mlp_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, x, weights, biases, y, npix, P, d);
+        int maxw = 0;
+        for (int l = 0; l <= nlayers; ++l) maxw = widths_host[l] > maxw ? widths_host[l] : maxw;
+        return maxw <= 32 ? launch_fwd_uniform<1>(x, weights, biases, y, npix, P, d, s) : launch_fwd_uniform<2>(x, weights, biases, y, npix, P, d, s);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(pixel_mlp_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, x, weights, biases, y, npix, P, d);
+        hipLaunchKernelGGL(pixel_mlp_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kGenThreads), lds, s, x, weights, biases, y, npix, P, d);
     }
     return check_launch("pixel_mlp_fwd");
 }
