@@ -245,12 +245,20 @@ __device__ void stage_uniform(const PixelMlpDesc& d, const float* __restrict__ W
 // so the sites are visited in channel order and the walk stops (uniformly) at the first site beyond the channel count --
 // 3 channels touch 3 sites, not 64.  Loads are unconditional (pixel and channel clamped into range) and zeroed by a
 // select; stores are masked per lane.
-template <int SS>
+template <int SS, bool SMALL>
 __device__ __forceinline__ void load_frags(const float* __restrict__ xb, size_t P, int cin0, bool ok, int h, bf16x8 (&f)[SS]) {
 #pragma unroll
     for (int s = 0; s < SS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[s][j] = 0;
+    if constexpr (SMALL) {      // cin0 <= 4, the usual (u, v, p) input: channels 0..3 sit in elements 0..3 of fragment 0, lane half 0 only
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = xb[(size_t)(j < cin0 ? j : 0) * P];
+            f[0][j] = (short)f2bf((ok && h == 0 && j < cin0) ? v : 0.f);
+        }
+        return;
+    } else {
 #pragma unroll
     for (int s = 0; s < SS; ++s)
 #pragma unroll
@@ -261,10 +269,19 @@ __device__ __forceinline__ void load_frags(const float* __restrict__ xb, size_t 
             const float v = xb[(size_t)(c < cin0 ? c : cin0 - 1) * P];
             f[s][j] = (short)f2bf((ok && c < cin0) ? v : 0.f);
         }
+    }
 }
 
-template <int OT>
+template <int OT, bool SMALL>
 __device__ __forceinline__ void store_acc(float* __restrict__ yb, size_t P, int cout, int h, const f32x16 (&a)[OT]) {
+    if constexpr (SMALL) {            // channels 0..3 = registers 0..3 of tile 0, lane half 0
+        if (h == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < cout) yb[(size_t)i * P] = a[0][i];
+        }
+        return;
+    } else {
 #pragma unroll
     for (int t = 0; t < OT; ++t)
 #pragma unroll
@@ -274,6 +291,7 @@ __device__ __forceinline__ void store_acc(float* __restrict__ yb, size_t P, int 
             const int c = rmin + 4 * h;
             if (c < cout) yb[(size_t)c * P] = a[t][i];
         }
+    }
 }
 
 // PT = 2 pixel tiles (64 pixels) per wave and pass: every weight fragment read from LDS feeds two MFMAs and the bias
@@ -281,7 +299,7 @@ __device__ __forceinline__ void store_acc(float* __restrict__ yb, size_t P, int 
 // fragments + 8 KB of bias per 256 MFMA cycles of ONE SIMD, i.e. the CU's whole 128 B/clk, twice over.
 constexpr int kPT = 2;
 
-template <int OT>
+template <int OT, bool SMALLIO>
 __global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void pixel_mlp_fwd_uniform_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
                                                                              float* __restrict__ y, long npix_total, int P, PixelMlpDesc d) {
     using U = UniLds<OT>;
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
             const long gp = (g * kPT + pt) * 32 + r;
             const bool ok = g < ngroups && gp < npix_total;
             const long gc = ok ? gp : npix_total - 1;                       // clamped: the load itself is unconditional
-            load_frags<SS>(x + (size_t)(gc / P) * cin0 * P + gc % P, (size_t)P, cin0, ok, h, f[pt]);
+            load_frags<SS, SMALLIO>(x + (size_t)(gc / P) * cin0 * P + gc % P, (size_t)P, cin0, ok, h, f[pt]);
         }
     };
     for (long g = (long)blockIdx.x * kFwdWaves + wave; g < ngroups; g += gstride) {
@@ -353,21 +371,21 @@ __global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
         for (int pt = 0; pt < kPT; ++pt) {
             const long gp = (g * kPT + pt) * 32 + r;
-            if (gp < npix_total) store_acc<OT>(y + (size_t)(gp / P) * coutL * P + gp % P, (size_t)P, coutL, h, acc[pt]);
+            if (gp < npix_total) store_acc<OT, SMALLIO>(y + (size_t)(gp / P) * coutL * P + gp % P, (size_t)P, coutL, h, acc[pt]);
         }
     }
 }
 
-template <int OT>
+template <int OT, bool SMALLIO>
 int launch_fwd_uniform(const float* x, const float* weights, const float* biases, float* y, long npix, int P, const PixelMlpDesc& d, hipStream_t s) {
     const int lds = UniLds<OT>::total(d.nlayers);
     if (lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_fwd: weights need %d B of LDS (> 160 KiB)", lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_uniform_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_uniform_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const long ngroups = (npix + 32 * kPT - 1) / (32 * kPT);
     // persistent: one generation of workgroups (2 per CU fit by LDS), so the weights are staged once per workgroup
     long blocks = (ngroups + kFwdWaves - 1) / kFwdWaves; if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(pixel_mlp_fwd_uniform_kernel<OT>, dim3((unsigned)blocks), dim3(kFwdThreads), lds, s, x, weights, biases, y, npix, P, d);
+    hipLaunchKernelGGL((pixel_mlp_fwd_uniform_kernel<OT, SMALLIO>), dim3((unsigned)blocks), dim3(kFwdThreads), lds, s, x, weights, biases, y, npix, P, d);
     return check_launch("pixel_mlp_fwd");
 }
 
@@ -376,76 +394,135 @@ int launch_fwd_uniform(const float* x, const float* weights, const float* biases
 //     gx = dL/dx,   gW_l = sum_pix delta_l a_{l-1}^T,   gb_l = sum_pix delta_l          given gy = dL/dy,
 // WITHOUT activations saved by the forward: a workgroup (4 waves, one 32-pixel tile each = a 128-pixel super-tile)
 // recomputes the forward in registers, keeping every layer's INPUT as the bf16 operand fragments the forward MFMAs
-// consumed (16 VGPRs per 64-channel layer), then walks the layers backwards:
+// consume (8 OT VGPRs per layer), then walks the layers backwards:
 //   * data chain   delta_{l-1}^T[in x pix] = W_l^T[in x out] delta_l^T[out x pix]  -- the same accumulator-as-operand
-//     chaining as the forward, with fragments of W^T staged in LDS; ReLU mask from the stored fragments' sign;
+//     chaining as the forward; its MFMAs are issued FIRST so that they run under the image writes below; ReLU mask
+//     from the stored input fragments (a_{l-1} != 0);
 //   * weight grads sum over the PIXEL index, which sits on the lanes of both delta_l and a_{l-1}: one transpose is
-//     unavoidable.  Each wave stores its tiles as bf16 rows of two [128 pix][64 ch] LDS images (8-byte stores) and,
-//     after a barrier, every wave owns one 32x32 block of gW_l (out block = wave>>1, in block = wave&1) and reads its
-//     A = delta and B = activation fragments over all 128 pixels with ds_read_b64_tr_b16 (hardware transpose): 8 MFMAs
-//     per layer, accumulated in registers across all super-tiles of the workgroup (16 VGPRs per layer);
-//   * bias grads   from the delta fragments the in-block-0 waves read anyway (VALU adds beside the MFMAs).
-// Per layer and tile: 8 (forward) + 8 (data) + 8 (weights) MFMA 32x32x16 = the minimum.  Partial gradients go to a
-// per-workgroup workspace slice; pixel_mlp_reduce_kernel adds the slices in a fixed order (deterministic).
+//     unavoidable.  Each wave stores its tiles as bf16 rows of two [128 pix][32 OT ch] LDS images (8-byte stores) and,
+//     after a barrier, reads A = delta and B = activation fragments over the 128 pixels with ds_read_b64_tr_b16
+//     (hardware transpose).  OT = 2: each wave owns one 32x32 block of the 64x64 gW_l; OT = 1: the single block's K
+//     range (128 pixels) is split over the four waves.  Accumulated in registers across all super-tiles;
+//   * bias grads   v_dot2c_f32_bf16 with ones on the delta fragments already read for the weight grads.
+// Like the forward, every layer is padded to one compile-time square shape (32 OT)^2, so nothing inside a layer
+// branches.  The weights live in LDS ONCE, as plain bf16 [out][in] matrices (padded rows): the forward's A fragments
+// are two 8-byte reads of a row, the transposed product's A fragments two transposing reads of a 4 x 16 block.
+// Per layer and tile: 8 + 8 + 8 (OT = 2) MFMA 32x32x16.  Partial gradients go to per-workgroup (OT = 2) or per-wave
+// (OT = 1) workspace slices; pixel_mlp_reduce_kernel adds the slices in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------------------------
 using bf16x4 = __attribute__((ext_vector_type(4))) short;
-constexpr int kImgStride = 144;                 // bytes per pixel row of an exchange image: 64 ch * 2 B + 16 B pad
-constexpr int kImgBytes = 128 * kImgStride;
+using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
 
-struct PixelMlpBwdDesc {
-    PixelMlpDesc f;                              // forward fragments + biases
-    int lds_wt[kMaxLayers];                      // offset (bytes) of the W^T fragments
-    int lds_img_d, lds_img_a;                    // exchange images
-    int nparams_w, nparams;                      // packed weight count, weight + bias count
+template <int OT>
+struct BwdLds {
+    static constexpr int SS = 2 * OT, CH = 32 * OT;
+    static constexpr int ROWB = CH * 2 + 16;                  // bytes per weight row / image row (8-byte multiple, skews banks)
+    static constexpr int W_BYTES = CH * ROWB;
+    static constexpr int B_BYTES = CH * 4;
+    static constexpr int IMG_BYTES = 128 * ROWB;
+    __host__ __device__ static int total(int nl) { return nl * (W_BYTES + B_BYTES) + 2 * IMG_BYTES; }
 };
 
-// fragments of W^T for the data chain: [it = in/32][s = out/16][lane 64][8] bf16 = W[16 s + 8 (j>>2) + 4 (lane>>5) + (j&3)][32 it + (lane&31)]
-__device__ void stage_weights_t(const PixelMlpBwdDesc& d, const float* __restrict__ W, unsigned char* lds, int tid, int nthreads) {
-    for (int l = 0; l < d.f.nlayers; ++l) {
-        const int cin = d.f.cin[l], cout = d.f.cout[l];
-        const int its = (cin + 31) / 32, ss = (cout + 15) / 16;
-        const float* Wl = W + d.f.woff[l];
-        unsigned short* dst = reinterpret_cast<unsigned short*>(lds + d.lds_wt[l]);
-        for (int e = tid; e < its * ss * 64 * 8; e += nthreads) {
-            const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) % ss, it = (e >> 9) / ss;
-            const int row = 32 * it + (lane & 31), k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-            dst[e] = f2bf((row < cin && k < cout) ? Wl[k * cin + row] : 0.f);
-        }
-    }
-}
-
-__device__ __forceinline__ float bf2f(short b) { return __builtin_bit_cast(float, (unsigned)(unsigned short)b << 16); }
-
-// 8 consecutive pixels (pix0 .. pix0+7, pix0 = 16 s + 8 (lane>>5)) of channel  ch_block + (lane&31)  from a [pix][ch] image:
-// two transposing reads of 4 pixel rows each.  Lane 4q+p of a 16-lane group addresses row q, channels 4p..4p+3 of the
-// group's 4 x 16 block; lane i receives channel i of the four rows.  EXEC must be all ones here.
-__device__ __forceinline__ bf16x8 read_tr8(const unsigned char* img, int lane, int s, int ch_block) {
-    const int gl = lane & 15, q = gl >> 2, pp = gl & 3;
-    const int ch0 = ch_block + 16 * ((lane >> 4) & 1), pix0 = 16 * s + 8 * (lane >> 5);
-    const unsigned char* a0 = img + (pix0 + q) * kImgStride + (ch0 + 4 * pp) * 2;
-    using lds_v4 = __attribute__((address_space(3))) bf16x4;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * kImgStride));
+__device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
 
-__global__ __launch_bounds__(256) void pixel_mlp_bwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                  const float* __restrict__ W, const float* __restrict__ Bv,
-                                                                  float* __restrict__ gx, float* __restrict__ ws,
-                                                                  long npix_total, int P, PixelMlpBwdDesc d) {
+// A fragment of the forward product, rows 32 ot + r of the plain [out][in] image, k-step s
+template <int ROWB>
+__device__ __forceinline__ bf16x8 frag_w(const unsigned char* wimg, int r, int h, int ot, int s) {
+    const unsigned char* a = wimg + (32 * ot + r) * ROWB + (16 * s + 4 * h) * 2;
+    return join8(*reinterpret_cast<const bf16x4*>(a), *reinterpret_cast<const bf16x4*>(a + 16));
+}
+
+// Transposing fragment read: element j of lane (r, h) = M[row0 + 16 s + 8 (j>>2) + 4 h + (j&3)][col_block + r] of a plain
+// [rows][cols] bf16 image (row stride ROWB bytes).  Lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of
+// the group's 4 x 16 block; lane i receives column i of the four rows.  EXEC must be all ones here.
+template <int ROWB>
+__device__ __forceinline__ bf16x8 frag_t(const unsigned char* img, int lane, int s, int col_block) {
+    const int gl = lane & 15, q = gl >> 2, pp = gl & 3;
+    const int c0 = col_block + 16 * ((lane >> 4) & 1), row0 = 16 * s + 4 * (lane >> 5);
+    const unsigned char* a0 = img + (row0 + q) * ROWB + (c0 + 4 * pp) * 2;
+    using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 8 * ROWB)));
+}
+
+// 8 consecutive pixels (16 s + 8 h .. +7) of channel ch_block + r from a [pix][ch] image
+template <int ROWB>
+__device__ __forceinline__ bf16x8 frag_pix(const unsigned char* img, int lane, int s, int ch_block) {
+    const int gl = lane & 15, q = gl >> 2, pp = gl & 3;
+    const int c0 = ch_block + 16 * ((lane >> 4) & 1), pix0 = 16 * s + 8 * (lane >> 5);
+    const unsigned char* a0 = img + (pix0 + q) * ROWB + (c0 + 4 * pp) * 2;
+    using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ROWB)));
+}
+
+template <int OT, bool SMALL>
+__device__ __forceinline__ void load_acc(const float* __restrict__ gb, size_t P, int cout, bool ok, int h, f32x16 (&a)[OT]) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[t][i] = 0.f;
+    if constexpr (SMALL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = gb[(size_t)(i < cout ? i : 0) * P];
+            a[0][i] = (ok && h == 0 && i < cout) ? v : 0.f;
+        }
+        return;
+    } else {
+#pragma unroll
+    for (int t = 0; t < OT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rmin = 32 * t + (i & 3) + 8 * (i >> 2);
+            if (rmin >= cout) return;
+            const int c = rmin + 4 * h;
+            const float v = gb[(size_t)(c < cout ? c : cout - 1) * P];
+            a[t][i] = (ok && c < cout) ? v : 0.f;
+        }
+    }
+}
+
+template <int OT, bool SMALLIO>
+__global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                     const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                     float* __restrict__ gx, float* __restrict__ ws,
+                                                                     long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
+    using U = BwdLds<OT>;
+    constexpr int SS = U::SS, ROWB = U::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    stage_weights<true>(d.f, W, Bv, lds, threadIdx.x, 256);
-    stage_weights_t(d, W, lds, threadIdx.x, 256);
-    unsigned char* imgD = lds + d.lds_img_d;
-    unsigned char* imgA = lds + d.lds_img_a;
-    for (int e = threadIdx.x; e < 2 * kImgBytes / 4; e += 256) reinterpret_cast<unsigned*>(imgD)[e] = 0u;   // images are contiguous; pads stay 0
-    __syncthreads();
+    const int nl = d.nlayers;
+    {   // stage: zero everything (pads, images), then scatter the real matrices (coalesced reads)
+        const int total = U::total(nl);
+        for (int e = threadIdx.x; e < total / 16; e += 256) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int l = 0; l < nl; ++l) {
+            const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
+            const float* Wl = W + d.woff[l];
+            unsigned char* dst = lds + l * U::W_BYTES;
+            int row = threadIdx.x / cin, k = threadIdx.x - row * cin;
+            const int drow = 256 / cin, dk = 256 - drow * cin;
+            for (int e = threadIdx.x; e < n; e += 256) {
+                *reinterpret_cast<unsigned short*>(dst + row * ROWB + k * 2) = f2bf(Wl[e]);
+                row += drow; k += dk;
+                if (k >= cin) { k -= cin; ++row; }
+            }
+            float* bl = reinterpret_cast<float*>(lds + nl * U::W_BYTES + l * U::B_BYTES);
+            for (int e = threadIdx.x; e < cout; e += 256) bl[e] = Bv[d.boff[l] + e];
+        }
+        __syncthreads();
+    }
+    const unsigned char* bias0 = lds + nl * U::W_BYTES;
+    unsigned char* imgD = lds + nl * (U::W_BYTES + U::B_BYTES);
+    unsigned char* imgA = imgD + U::IMG_BYTES;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
-    const int bo = wave >> 1, bi = wave & 1;
-    const int nl = d.f.nlayers;
-    const int cin0 = d.f.cin[0], coutL = d.f.cout[nl - 1];
+    const int bo = OT == 2 ? wave >> 1 : 0, bi = OT == 2 ? wave & 1 : 0;       // this wave's gW block
+    constexpr int KS = OT == 2 ? 8 : 2;                                       // its k-steps (of 8 x 16 pixels)
+    const int ks0 = OT == 2 ? 0 : 2 * wave;
+    const bool do_gb = OT == 2 ? bi == 0 : true;
+    const int cin0 = d.cin[0], coutL = d.cout[nl - 1];
 
     f32x16 gw[kMaxLayers];
     float gbp[kMaxLayers];
@@ -459,147 +536,116 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_bf16_kernel(const float* __
     for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
         const long gp = sup * 128 + wave * 32 + r;
         const bool ok = gp < npix_total;
-        const long b = ok ? gp / P : 0, p = ok ? gp % P : 0;
-        // ---------------- forward, keeping every layer's input fragments
-        bf16x8 afrag[kMaxLayers][4];
-        f32x16 act[2];
-        {
-            const float* xb = x + (size_t)b * cin0 * P + p;
+        const long gc = ok ? gp : npix_total - 1;
+        const long b = gc / P, p = gc % P;
+        // ---------------- forward: afrag[l] = input fragments of layer l
+        bf16x8 afrag[kMaxLayers][SS];
+        load_frags<SS, SMALLIO>(x + (size_t)b * cin0 * P + p, (size_t)P, cin0, ok, h, afrag[0]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int l = 0; l + 1 < kMaxLayers; ++l) {
+            if (l + 1 < nl) {
+                __builtin_amdgcn_sched_barrier(0);            // phase boundaries: keep fragment loads from being hoisted across
+                const unsigned char* wimg = lds + l * U::W_BYTES;
+                const float* bl = reinterpret_cast<const float*>(bias0 + l * U::B_BYTES);
+                f32x16 acc[OT];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); act[t][i] = (ok && c < cin0) ? xb[(size_t)c * P] : 0.f; }
-        }
+                for (int ot = 0; ot < OT; ++ot) {
 #pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) {
-            if (l < nl) {
-                const int cin = d.f.cin[l], cout = d.f.cout[l];
-                const int ots = (cout + 31) / 32, ss = (cin + 15) / 16;
+                    for (int i = 0; i < 16; ++i) acc[ot][i] = bl[32 * ot + acc_row(i, h)];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<ROWB>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
+                }
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) afrag[l][s][j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
-                if (l + 1 < nl) {                                            // the last layer's output is not needed
-                    const float* bl = reinterpret_cast<const float*>(lds + d.f.lds_bias[l]);
-                    const bf16x8* wl = reinterpret_cast<const bf16x8*>(lds + d.f.lds_off[l]);
-                    f32x16 out[2];
+                for (int s = 0; s < SS; ++s) {
+                    bf16x8 t;
 #pragma unroll
-                    for (int ot = 0; ot < 2; ++ot) {
-                        if (ot < ots) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) out[ot][i] = bl[32 * ot + acc_row(i, h)];
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                if (s < ss) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[(ot * ss + s) * 64 + lane], afrag[l][s], out[ot], 0, 0, 0);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) out[ot][i] = 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) act[t][i] = fmaxf(out[t][i], 0.f);
+                    for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(acc[s >> 1][8 * (s & 1) + j]);
+                    afrag[l + 1][s] = __builtin_elementwise_max(t, zero);
                 }
             }
         }
         // ---------------- backward
-        f32x16 dl[2];
+        bf16x8 dfrag[SS];
         {
-            const float* gb = gy + (size_t)b * coutL * P + p;
+            f32x16 dl[OT];
+            load_acc<OT, SMALLIO>(gy + (size_t)b * coutL * P + p, (size_t)P, coutL, ok, h, dl);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int s = 0; s < SS; ++s)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); dl[t][i] = (ok && c < coutL) ? gb[(size_t)c * P] : 0.f; }
+                for (int j = 0; j < 8; ++j) dfrag[s][j] = (short)f2bf(dl[s >> 1][8 * (s & 1) + j]);
         }
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
             if (l < nl) {
-                const int cin = d.f.cin[l], cout = d.f.cout[l];
-                // delta_l and a_{l-1} as bf16 rows [32 wave + r] of the images
-                bf16x8 dfrag[4];
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wimg = lds + l * U::W_BYTES;
+                // data chain first: its MFMAs run while the images are written
+                f32x16 nd[OT];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int it = 0; it < OT; ++it) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dfrag[s][j] = (short)f2bf(dl[s >> 1][8 * (s & 1) + j]);
-                {
-                    unsigned char* rowD = imgD + (32 * wave + r) * kImgStride;
-                    unsigned char* rowA = imgA + (32 * wave + r) * kImgStride;
+                    for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
+                    for (int s = 0; s < SS; ++s) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<ROWB>(wimg, lane, s, 32 * it), dfrag[s], nd[it], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // delta_l and a_{l-1} as bf16 rows [32 wave + r] of the images
+                    unsigned char* rowD = imgD + (32 * wave + r) * ROWB;
+                    unsigned char* rowA = imgA + (32 * wave + r) * ROWB;
+#pragma unroll
+                    for (int s = 0; s < SS; ++s) {
                         // fragment elements 0..3 = channels 16 s + 4 h + (0..3), elements 4..7 = channels 16 s + 8 + 4 h + (0..3)
-                        bf16x4 d0, d1, a0, a1;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { d0[j] = dfrag[s][j]; d1[j] = dfrag[s][4 + j]; a0[j] = afrag[l][s][j]; a1[j] = afrag[l][s][4 + j]; }
-                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 4 * h) * 2) = d0;
-                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 8 + 4 * h) * 2) = d1;
-                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 4 * h) * 2) = a0;
-                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = a1;
+                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
+                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
                     }
                 }
                 __syncthreads();
-                if (32 * bo < cout && 32 * bi < cin) {                       // wave-uniform: EXEC stays full for the transposing reads
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const bf16x8 fa = read_tr8(imgD, lane, s, 32 * bo);
-                        const bf16x8 fb = read_tr8(imgA, lane, s, 32 * bi);
-                        gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
-                        if (bi == 0) {
-                            float sum = 0.f;
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 fa = frag_pix<ROWB>(imgD, lane, ks0 + kk, 32 * bo);
+                    const bf16x8 fb = frag_pix<ROWB>(imgA, lane, ks0 + kk, 32 * bi);
+                    gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                    if (kk & 1) __builtin_amdgcn_sched_barrier(0);
+                    if (do_gb) {
+                        const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) sum += bf2f(fa[j]);
-                            gbp[l] += sum;
+                        for (int j = 0; j < 8; j += 2) {
+                            const unsigned pr = (unsigned)(unsigned short)fa[j] | ((unsigned)(unsigned short)fa[j + 1] << 16);
+                            gbp[l] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pr), ones, gbp[l], false);
                         }
                     }
                 }
                 __syncthreads();
-                // data chain: delta_{l-1} (or gx for l = 0)
-                {
-                    const int its = (cin + 31) / 32, ss = (cout + 15) / 16;
-                    const bf16x8* wt = reinterpret_cast<const bf16x8*>(lds + d.lds_wt[l]);
-                    f32x16 nd[2];
+                if (l > 0) {
+                    // ReLU mask a_{l-1} != 0 (activations are >= 0), then the next layer's operand fragments
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) {
+                    for (int s = 0; s < SS; ++s)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
-                        if (it < its) {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                if (s < ss) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[(it * ss + s) * 64 + lane], dfrag[s], nd[it], 0, 0, 0);
-                        }
-                    }
-                    if (l > 0) {
-                        // ReLU mask: a_{l-1} > 0, read off the stored fragments (register i of tile t = element i&7 of fragment 2t + (i>>3))
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) dl[t][i] = afrag[l][2 * t + (i >> 3)][i & 7] > 0 ? nd[t][i] : 0.f;
-                    } else if (ok) {
-                        float* gxb = gx + (size_t)b * cin0 * P + p;
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) { const int c = 32 * t + acc_row(i, h); if (c < cin0) gxb[(size_t)c * P] = nd[t][i]; }
-                    }
+                        for (int j = 0; j < 8; ++j) dfrag[s][j] = afrag[l][s][j] != 0 ? (short)f2bf(nd[s >> 1][8 * (s & 1) + j]) : (short)0;
+                } else if (ok) {
+                    store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
             }
         }
     }
-    // ---------------- this workgroup's partial gradients
-    float* wsb = ws + (size_t)blockIdx.x * d.nparams;
+    // ---------------- partial gradients: workspace slice per workgroup (OT = 2) or per wave (OT = 1)
+    float* wsb = ws + (size_t)(OT == 2 ? blockIdx.x : blockIdx.x * 4 + wave) * nparams;
 #pragma unroll
     for (int l = 0; l < kMaxLayers; ++l) {
         if (l < nl) {
-            const int cin = d.f.cin[l], cout = d.f.cout[l];
+            const int cin = d.cin[l], cout = d.cout[l];
             const int in = 32 * bi + r;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int out = 32 * bo + acc_row(i, h);
-                if (out < cout && in < cin) wsb[d.f.woff[l] + out * cin + in] = gw[l][i];
+                if (out < cout && in < cin) wsb[d.woff[l] + out * cin + in] = gw[l][i];
             }
-            if (bi == 0) {
+            if (do_gb) {
                 const float tot = gbp[l] + __shfl_xor(gbp[l], 32);
-                if (h == 0 && 32 * bo + r < cout) wsb[d.nparams_w + d.f.boff[l] + 32 * bo + r] = tot;
+                if (h == 0 && 32 * bo + r < cout) wsb[nparams_w + d.boff[l] + 32 * bo + r] = tot;
             }
         }
     }
@@ -615,26 +661,37 @@ __global__ void pixel_mlp_reduce_kernel(const float* __restrict__ ws, float* __r
 
 constexpr int kBwdMaxBlocks = 256;
 
-int build_bwd_desc(const int* widths_host, int nlayers, PixelMlpBwdDesc& d, int& lds_total) {
+int build_bwd_desc(const int* widths_host, int nlayers, PixelMlpDesc& d, int& nparams_w, int& nparams, int& maxw) {
     if (nlayers < 1 || nlayers > kMaxLayers) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: %d layers (1..%d supported)", nlayers, kMaxLayers);
-    d.f.nlayers = nlayers;
-    int woff = 0, boff = 0, lds = 0;
-    for (int l = 0; l < kMaxLayers; ++l) { d.f.cin[l] = d.f.cout[l] = 1; d.f.woff[l] = d.f.boff[l] = d.f.lds_off[l] = d.f.lds_bias[l] = 0; d.lds_wt[l] = 0; }
+    d.nlayers = nlayers;
+    int woff = 0, boff = 0;
+    maxw = 0;
+    for (int l = 0; l < kMaxLayers; ++l) { d.cin[l] = d.cout[l] = 1; d.woff[l] = d.boff[l] = d.lds_off[l] = d.lds_bias[l] = 0; }
     for (int l = 0; l < nlayers; ++l) {
         const int cin = widths_host[l], cout = widths_host[l + 1];
         if (cin < 1 || cout < 1 || cin > kMaxWidth || cout > kMaxWidth) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: layer %d is %d -> %d (widths 1..%d supported)", l, cin, cout, kMaxWidth);
-        d.f.cin[l] = cin; d.f.cout[l] = cout; d.f.woff[l] = woff; d.f.boff[l] = boff;
+        d.cin[l] = cin; d.cout[l] = cout; d.woff[l] = woff; d.boff[l] = boff;
         woff += cin * cout; boff += cout;
-        d.f.lds_off[l] = lds;  lds += ((cout + 31) / 32) * ((cin + 15) / 16) * 64 * 16;
-        d.f.lds_bias[l] = lds; lds += ((cout + 31) / 32) * 32 * 4;
-        d.lds_wt[l] = lds;     lds += ((cin + 31) / 32) * ((cout + 15) / 16) * 64 * 16;
+        maxw = cin > maxw ? cin : maxw; maxw = cout > maxw ? cout : maxw;
     }
-    d.lds_img_d = lds; lds += kImgBytes;
-    d.lds_img_a = lds; lds += kImgBytes;
-    d.nparams_w = woff; d.nparams = woff + boff;
-    lds_total = lds;
-    if (lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: needs %d B of LDS (> 160 KiB)", lds);
+    nparams_w = woff; nparams = woff + boff;
     return NNS_OK;
+}
+
+template <int OT, bool SMALLIO>
+int launch_bwd_uniform(const float* x, const float* gy, const float* weights, const float* biases, float* gx, float* gW, float* gB,
+                       long npix, int P, const PixelMlpDesc& d, int nparams_w, int nparams, float* ws, hipStream_t s) {
+    const int lds = BwdLds<OT>::total(d.nlayers);
+    if (lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: needs %d B of LDS (> 160 KiB)", lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_uniform_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+    const long nsuper = (npix + 127) / 128;
+    const int blocks = (int)(nsuper < kBwdMaxBlocks ? nsuper : kBwdMaxBlocks);
+    hipLaunchKernelGGL((pixel_mlp_bwd_uniform_kernel<OT, SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
+    if (int rc = check_launch("pixel_mlp_bwd")) return rc;
+    const int nslices = blocks * (OT == 2 ? 1 : 4);
+    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((nparams + 255) / 256), dim3(256), 0, s, ws, gW, gB, nslices, nparams_w, nparams);
+    return check_launch("pixel_mlp_reduce");
 }
 
 }  // namespace
@@ -671,7 +728,9 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
     if (bf16) {
         int maxw = 0;
         for (int l = 0; l <= nlayers; ++l) maxw = widths_host[l] > maxw ? widths_host[l] : maxw;
-        return maxw <= 32 ? launch_fwd_uniform<1>(x, weights, biases, y, npix, P, d, s) : launch_fwd_uniform<2>(x, weights, biases, y, npix, P, d, s);
+        const bool small = widths_host[0] <= 4 && widths_host[nlayers] <= 4;          // (u, v, p)-sized input and output: straight-line tile I/O
+        if (maxw <= 32) return small ? launch_fwd_uniform<1, true>(x, weights, biases, y, npix, P, d, s) : launch_fwd_uniform<1, false>(x, weights, biases, y, npix, P, d, s);
+        return small ? launch_fwd_uniform<2, true>(x, weights, biases, y, npix, P, d, s) : launch_fwd_uniform<2, false>(x, weights, biases, y, npix, P, d, s);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -685,9 +744,9 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
 // no backward yet: bf16 == 0 fails with NNS_ERR_UNSUPPORTED.
 NNS_API int nns_pixel_mlp_bwd_workspace(const int* widths_host, int nlayers, size_t* bytes) {
     if (!widths_host || !bytes) return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd_workspace: bad args");
-    PixelMlpBwdDesc d; int lds;
-    if (int rc = build_bwd_desc(widths_host, nlayers, d, lds)) return rc;
-    *bytes = (size_t)kBwdMaxBlocks * d.nparams * sizeof(float);
+    PixelMlpDesc d; int nw, np, maxw;
+    if (int rc = build_bwd_desc(widths_host, nlayers, d, nw, np, maxw)) return rc;
+    *bytes = (size_t)kBwdMaxBlocks * (maxw <= 32 ? 4 : 1) * np * sizeof(float);
     return NNS_OK;
 }
 
@@ -697,18 +756,17 @@ NNS_API int nns_pixel_mlp_bwd_f32(const float* x, const float* gy, const float* 
     if (!x || !gy || !weights || !biases || !gx || !gW || !gB || !widths_host || !workspace || mb < 1 || P < 1)
         return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: bad args");
     if (!bf16) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: only the bf16 mode has a backward kernel");
-    PixelMlpBwdDesc d; int lds;
-    if (int rc = build_bwd_desc(widths_host, nlayers, d, lds)) return rc;
-    if (workspace_bytes < (size_t)kBwdMaxBlocks * d.nparams * sizeof(float))
+    PixelMlpDesc d; int nw, np, maxw;
+    if (int rc = build_bwd_desc(widths_host, nlayers, d, nw, np, maxw)) return rc;
+    if (workspace_bytes < (size_t)kBwdMaxBlocks * (maxw <= 32 ? 4 : 1) * np * sizeof(float))
         return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: workspace too small (%zu B, see nns_pixel_mlp_bwd_workspace)", workspace_bytes);
-    const long npix = (long)mb * P;
-    const long nsuper = (npix + 127) / 128;
-    const int blocks = (int)(nsuper < kBwdMaxBlocks ? nsuper : kBwdMaxBlocks);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(pixel_mlp_bwd_bf16_kernel, dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, static_cast<float*>(workspace), npix, P, d);
-    if (int rc = check_launch("pixel_mlp_bwd")) return rc;
-    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((d.nparams + 255) / 256), dim3(256), 0, s, static_cast<const float*>(workspace), gW, gB, blocks, d.nparams_w, d.nparams);
-    return check_launch("pixel_mlp_reduce");
+    const long npix = (long)mb * P;
+    float* ws = static_cast<float*>(workspace);
+    const bool small = widths_host[0] <= 4 && widths_host[nlayers] <= 4;
+    if (maxw <= 32)
+        return small ? launch_bwd_uniform<1, true>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s)
+                     : launch_bwd_uniform<1, false>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s);
+    return small ? launch_bwd_uniform<2, true>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s)
+                 : launch_bwd_uniform<2, false>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s);
 }
