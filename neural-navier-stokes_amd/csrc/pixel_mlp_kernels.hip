@@ -300,7 +300,7 @@ __device__ __forceinline__ void store_acc(float* __restrict__ yb, size_t P, int 
 constexpr int kPT = 2;
 
 template <int OT, bool SMALLIO>
-__global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void pixel_mlp_fwd_uniform_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
+__global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 3))) void pixel_mlp_fwd_uniform_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
                                                                              float* __restrict__ y, long npix_total, int P, PixelMlpDesc d) {
     using U = UniLds<OT>;
     constexpr int SS = U::SS;
@@ -416,7 +416,10 @@ using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
 template <int OT>
 struct BwdLds {
     static constexpr int SS = 2 * OT, CH = 32 * OT;
-    static constexpr int ROWB = CH * 2 + 16;                  // bytes per weight row / image row (8-byte multiple, skews banks)
+#ifndef NNS_PM_ROWPAD
+#define NNS_PM_ROWPAD 8
+#endif
+    static constexpr int ROWB = CH * 2 + NNS_PM_ROWPAD;       // bytes per weight row / image row (8-byte multiple, skews banks)
     static constexpr int W_BYTES = CH * ROWB;
     static constexpr int B_BYTES = CH * 4;
     static constexpr int IMG_BYTES = 128 * ROWB;
