@@ -106,6 +106,23 @@ int nns_fd_sor_f32(float* p, const float* C, float* info, void* work, int batch,
 int nns_fd_sor_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny,
                    double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
 
+/* ---- corrected / extended solver options (NOT reference behaviour) ----------------
+ * Explicit predictor with the true y-advection  v d/dy  (the reference differences along x twice, :73-76,:82-85);
+ * oracle: oracle/chorin_fd.py explicit_predictor_corrected. */
+int nns_fd_predictor_explicit_corrected_f32(const float* un, const float* vn, const float* un1, const float* vn1,
+                                            float* ui, float* vi, int batch, int nx, int ny,
+                                            double dt, double dx, double dy, double nu, void* stream);
+int nns_fd_predictor_explicit_corrected_f64(const double* un, const double* vn, const double* un1, const double* vn1,
+                                            double* ui, double* vi, int batch, int nx, int ny,
+                                            double dt, double dx, double dy, double nu, void* stream);
+/* Red-black SOR: the update formula, relaxation factor, stopping rule (max|p - pPrev| <= tol) and sweep cap of
+ * nns_fd_sor, with the points of one colour ((i + j) even, then odd) relaxed in parallel: two barriers per sweep
+ * instead of nx + ny fronts.  Same info layout; no workspace.  oracle: get_pressure_redblack (bitwise). */
+int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, int batch, int nx, int ny,
+                            double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
+int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, int batch, int nx, int ny,
+                            double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
+
 /* _correction_step (:204-210): u = u* - dt/(2dx) d0x p, v = v* - dt/(2dy) d0y p; edges from u*. */
 int nns_fd_correction_f32(const float* ui, const float* vi, const float* p, float* u, float* v,
                           int batch, int nx, int ny, double dt, double dx, double dy, void* stream);

@@ -78,7 +78,9 @@ int bc_apply(T* A, int batch, int nx, int ny, const nns_bc_list* h, hipStream_t 
 template <typename T>
 struct PredK { T dt, two_dx, two_dy, dx2, dy2, dt_nu; };
 
-template <typename T>
+// CORRECT = true: the build's "fixed y-advection" option (oracle:
+// explicit_predictor_corrected): v d/dy differences along y.  false: the reference's form (x-difference twice).
+template <typename T, bool CORRECT>
 __global__ __launch_bounds__(kTX) void predictor_explicit_kernel(const T* __restrict__ un, const T* __restrict__ vn,
                                                                   const T* __restrict__ un1, const T* __restrict__ vn1,
                                                                   T* __restrict__ ui, T* __restrict__ vi,
@@ -93,29 +95,32 @@ __global__ __launch_bounds__(kTX) void predictor_explicit_kernel(const T* __rest
     const T three_half = (T)1.5, half = (T)0.5, two = (T)2;
     {
         const T e = un[xp], w = un[xm], e1 = un1[xp], w1 = un1[xm];
-        const T adv = uc * (e - w) / k.two_dx + vc * (e - w) / k.two_dy;            // :73-74 (x-difference twice)
-        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (e1 - w1) / k.two_dy;      // :75-76
-        const T lap = (e - two * uc + w) / k.dx2 + (un[yp] - two * uc + un[ym]) / k.dy2;
-        const T lap1 = (e1 - two * u1c + w1) / k.dx2 + (un1[yp] - two * u1c + un1[ym]) / k.dy2;
+        const T n = un[yp], so = un[ym], n1 = un1[yp], so1 = un1[ym];
+        const T adv = uc * (e - w) / k.two_dx + vc * (CORRECT ? n - so : e - w) / k.two_dy;          // :73-74 (x-difference twice)
+        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (CORRECT ? n1 - so1 : e1 - w1) / k.two_dy;  // :75-76
+        const T lap = (e - two * uc + w) / k.dx2 + (n - two * uc + so) / k.dy2;
+        const T lap1 = (e1 - two * u1c + w1) / k.dx2 + (n1 - two * u1c + so1) / k.dy2;
         ui[c] = uc - k.dt * (three_half * adv - half * adv1) + k.dt_nu * (three_half * lap - half * lap1);
     }
     {
         const T e = vn[xp], w = vn[xm], e1 = vn1[xp], w1 = vn1[xm];
-        const T adv = uc * (e - w) / k.two_dx + vc * (e - w) / k.two_dy;            // :82-83
-        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (e1 - w1) / k.two_dy;
-        const T lap = (e - two * vc + w) / k.dx2 + (vn[yp] - two * vc + vn[ym]) / k.dy2;
-        const T lap1 = (e1 - two * v1c + w1) / k.dx2 + (vn1[yp] - two * v1c + vn1[ym]) / k.dy2;
+        const T n = vn[yp], so = vn[ym], n1 = vn1[yp], so1 = vn1[ym];
+        const T adv = uc * (e - w) / k.two_dx + vc * (CORRECT ? n - so : e - w) / k.two_dy;          // :82-83
+        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (CORRECT ? n1 - so1 : e1 - w1) / k.two_dy;
+        const T lap = (e - two * vc + w) / k.dx2 + (n - two * vc + so) / k.dy2;
+        const T lap1 = (e1 - two * v1c + w1) / k.dx2 + (n1 - two * v1c + so1) / k.dy2;
         vi[c] = vc - k.dt * (three_half * adv - half * adv1) + k.dt_nu * (three_half * lap - half * lap1);
     }
 }
 
 template <typename T>
 int predictor_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T* vi, int batch, int nx, int ny,
-                       double dt, double dx, double dy, double nu, hipStream_t s) {
+                       double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false) {
     if (!un || !vn || !un1 || !vn1 || !ui || !vi || !field_args_ok(batch, nx, ny))
         return fail(NNS_ERR_INVALID_ARG, "fd_predictor_explicit: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
     PredK<T> k{(T)dt, (T)(2 * dx), (T)(2 * dy), (T)(dx * dx), (T)(dy * dy), (T)(dt * nu)};
-    hipLaunchKernelGGL(predictor_explicit_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, un1, vn1, ui, vi, nx, ny, k);
+    if (corrected) hipLaunchKernelGGL((predictor_explicit_kernel<T, true>), grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, un1, vn1, ui, vi, nx, ny, k);
+    else hipLaunchKernelGGL((predictor_explicit_kernel<T, false>), grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, un1, vn1, ui, vi, nx, ny, k);
     return check_launch("fd_predictor_explicit");
 }
 
@@ -439,6 +444,14 @@ NNS_API int nns_bc_apply_f64(double* A, int batch, int nx, int ny, const nns_bc_
 NNS_API int nns_fd_predictor_explicit_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi,
                                           int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
     return predictor_explicit<float>(un, vn, un1, vn1, ui, vi, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+NNS_API int nns_fd_predictor_explicit_corrected_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi,
+                                                    int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_explicit<float>(un, vn, un1, vn1, ui, vi, batch, nx, ny, dt, dx, dy, nu, S(stream), true);
+}
+NNS_API int nns_fd_predictor_explicit_corrected_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi,
+                                                    int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_explicit<double>(un, vn, un1, vn1, ui, vi, batch, nx, ny, dt, dx, dy, nu, S(stream), true);
 }
 NNS_API int nns_fd_predictor_explicit_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi,
                                           int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {

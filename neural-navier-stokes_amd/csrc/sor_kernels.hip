@@ -134,6 +134,89 @@ int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double
     return check_launch("fd_sor");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Red-black SOR (oracle: get_pressure_redblack): the same update formula, relaxation
+// factor, stopping rule and sweep cap as the reference's loop, but points with (i + j) even are relaxed first, then the
+// odd ones.  A half-sweep only reads the other colour, so it is fully parallel: one workgroup per grid, every thread
+// a few points, two barriers per sweep (the lexicographic order needs nx + ny fronts per sweep).  p and C stay in LDS
+// when they fit; the error reduction is exact (max), so the result is bitwise the oracle's (no FMA contraction).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kRbThreads = 1024;
+
+template <typename T, bool IN_LDS>
+__global__ __launch_bounds__(kRbThreads) void sor_redblack_kernel(T* __restrict__ p, const T* __restrict__ C, T* __restrict__ info,
+                                                                   int nx, int ny, int max_sweeps, SorK<T> k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ T red[kRbThreads / kWave];
+    __shared__ T err_sh;
+    const int tid = threadIdx.x, n = nx * ny;
+    T* pg = p + (size_t)blockIdx.x * n;
+    const T* cg = C + (size_t)blockIdx.x * n;
+    T* pw = IN_LDS ? reinterpret_cast<T*>(smem) : pg;
+    const T* cw = IN_LDS ? reinterpret_cast<const T*>(smem) + n : cg;
+    if (IN_LDS) {
+        T* cl = reinterpret_cast<T*>(smem) + n;
+        for (int c = tid; c < n; c += kRbThreads) { pw[c] = pg[c]; cl[c] = cg[c]; }
+    }
+    __syncthreads();
+    const int mx = nx - 2, my = ny - 2, hw = (my + 1) / 2, half = mx * hw;     // points of one colour: <= hw per interior row
+    T err = (T)1;
+    int done = 0;
+    while (done < max_sweeps && err > k.tol) {
+        T emax = (T)0;
+#pragma unroll
+        for (int colour = 0; colour < 2; ++colour) {
+            for (int q = tid; q < half; q += kRbThreads) {
+                const int i = q / hw + 1;
+                const int j = 1 + 2 * (q % hw) + ((i + 1 + colour) & 1);        // (i + j) % 2 == colour
+                if (j > my) continue;
+                const int c = i * ny + j;
+                const T old = pw[c];
+                const T nw = k.beta * (k.dy2 * pw[c + ny] + k.dy2 * pw[c - ny] + k.dx2 * pw[c + 1] + k.dx2 * pw[c - 1] - cw[c]) / k.den + k.omb * old;
+                pw[c] = nw;
+                emax = nanmax<T>(emax, fabs(nw - old));
+            }
+            __syncthreads();
+        }
+        // workgroup max of |p - pPrev|
+        for (int off = kWave / 2; off > 0; off >>= 1) emax = nanmax<T>(emax, __shfl_xor(emax, off));
+        if ((tid & (kWave - 1)) == 0) red[tid / kWave] = emax;
+        __syncthreads();
+        if (tid == 0) {
+            T e = red[0];
+            for (int w = 1; w < kRbThreads / kWave; ++w) e = nanmax<T>(e, red[w]);
+            err_sh = e;
+        }
+        __syncthreads();
+        err = err_sh;
+        ++done;
+    }
+    __syncthreads();
+    if (IN_LDS) for (int c = tid; c < n; c += kRbThreads) pg[c] = pw[c];
+    if (tid == 0) { info[2 * blockIdx.x] = (T)done; info[2 * blockIdx.x + 1] = err; }
+}
+
+template <typename T>
+int sor_redblack(T* p, const T* C, T* info, int batch, int nx, int ny, double dx, double dy, double beta, double tol, int max_sweeps, hipStream_t s) {
+    if (!p || !C || !info || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
+        return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
+    const size_t lds = 2 * (size_t)nx * ny * sizeof(T);
+    if (lds <= 150 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_redblack_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor_redblack: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
+        hipLaunchKernelGGL((sor_redblack_kernel<T, true>), dim3(batch), dim3(kRbThreads), lds, s, p, C, info, nx, ny, max_sweeps, k);
+    } else {
+        hipLaunchKernelGGL((sor_redblack_kernel<T, false>), dim3(batch), dim3(kRbThreads), 0, s, p, C, info, nx, ny, max_sweeps, k);
+    }
+    return check_launch("fd_sor_redblack");
+}
+
 }  // namespace
 
 NNS_API size_t nns_fd_sor_workspace(int batch, int nx, int ny, int elem_size) {
@@ -147,4 +230,13 @@ NNS_API int nns_fd_sor_f32(float* p, const float* C, float* info, void* work, in
 NNS_API int nns_fd_sor_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny, double dx, double dy,
                            double beta, double tol, int max_sweeps, void* stream) {
     return sor<double>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+
+NNS_API int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, int batch, int nx, int ny, double dx, double dy,
+                                    double beta, double tol, int max_sweeps, void* stream) {
+    return sor_redblack<float>(p, C, info, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, int batch, int nx, int ny, double dx, double dy,
+                                    double beta, double tol, int max_sweeps, void* stream) {
+    return sor_redblack<double>(p, C, info, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
 }

@@ -32,9 +32,11 @@ _BCP = C.POINTER(BcList)
 _DUAL = {
     'nns_bc_apply': [_P, _I, _I, _I, _BCP, _P],
     'nns_fd_predictor_explicit': [_P] * 6 + [_I] * 3 + [_D] * 4 + [_P],
+    'nns_fd_predictor_explicit_corrected': [_P] * 6 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_predictor_adi': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_pressure_rhs': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_sor': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_fd_sor_redblack': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_correction': [_P] * 5 + [_I] * 3 + [_D] * 3 + [_P],
     'nns_fd_build_b': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_jacobi': [_P] * 3 + [_I] * 3 + [_D] * 2 + [_I, _BCP, _P],

@@ -27,7 +27,8 @@ SOR_TOL = 5e-6      # src/chorin_fd/simulate.py:183
 class NavierStokesSystem():
     def __init__(self, u_ic, v_ic, p_ic, u_bc, v_bc, p_bc,
                  nt=200, nit=50, nx=50, ny=50, dt=0.001,
-                 rho=1, nu=1, beta=1.25, method='semi_implicit', dtype=np.float64, device=None):
+                 rho=1, nu=1, beta=1.25, method='semi_implicit', dtype=np.float64, device=None,
+                 advection='reference', pressure_solver='sor'):
         self.u_ic, self.v_ic, self.p_ic = u_ic, v_ic, p_ic
         self.u_bc, self.v_bc, self.p_bc = u_bc, v_bc, p_bc
         self.nt, self.nit, self.dt, self.nx, self.ny = nt, nit, dt, nx, ny
@@ -35,6 +36,13 @@ class NavierStokesSystem():
         self.rho, self.nu, self.beta = rho, nu, beta
         assert method in ['semi_implicit', 'explicit']
         self.method = method
+        # Options beyond the reference; the defaults reproduce it bit for bit.
+        #   advection='corrected'      : explicit predictor with v d/dy along y (the reference differences along x twice)
+        #   pressure_solver='redblack' : red-black SOR (parallel half-sweeps) instead of the lexicographic order
+        assert advection in ['reference', 'corrected'] and pressure_solver in ['sor', 'redblack']
+        if advection == 'corrected' and method != 'explicit':
+            raise ValueError("advection='corrected' is available for method='explicit' only")
+        self.advection, self.pressure_solver = advection, pressure_solver
         self.dtype = np.dtype(dtype)
         self.device = device if device is not None else default_device()
         self._u_bcl = ops.make_bc_list(u_bc) if u_bc is not None else None
@@ -48,6 +56,8 @@ class NavierStokesSystem():
 
     def _predict_dev(self, u, v, u1, v1):
         if self.method == 'explicit':
+            if self.advection == 'corrected':
+                return ops.fd_predictor_explicit_corrected(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu)
             return ops.fd_predictor_explicit(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu)
         elif self.method == 'semi_implicit':
             return ops.fd_predictor_adi(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu)
@@ -55,7 +65,8 @@ class NavierStokesSystem():
 
     def _pressure_dev_(self, ui, vi, p):
         C = ops.fd_pressure_rhs(ui, vi, self.dt, self.dx, self.dy, self.rho)
-        self.last_sor_info = ops.fd_sor_(p, C, self.dx, self.dy, self.beta, SOR_TOL, max(int(self.nit) - 1, 0))
+        solve = ops.fd_sor_redblack_ if self.pressure_solver == 'redblack' else ops.fd_sor_
+        self.last_sor_info = solve(p, C, self.dx, self.dy, self.beta, SOR_TOL, max(int(self.nit) - 1, 0))
         return p
 
     def _step_dev(self, un, vn, un1, vn1, p):

@@ -90,6 +90,15 @@ def fd_predictor_explicit(un, vn, un1, vn1, dt, dx, dy, nu):
     return ui, vi
 
 
+def fd_predictor_explicit_corrected(un, vn, un1, vn1, dt, dx, dy, nu):
+    """The explicit predictor with the true y-advection (an option of the build, not reference behaviour)."""
+    suf, (B, nx, ny) = _chk(un, vn, un1, vn1)
+    ui, vi = torch.empty_like(un), torch.empty_like(vn)
+    _call('nns_fd_predictor_explicit_corrected', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(ui), _p(vi), B, nx, ny,
+          dt, dx, dy, nu, _stream())
+    return ui, vi
+
+
 def fd_predictor_adi(un, vn, un1, vn1, dt, dx, dy, nu):
     suf, (B, nx, ny) = _chk(un, vn, un1, vn1)
     ui, vi = torch.empty_like(un), torch.empty_like(vn)
@@ -114,6 +123,14 @@ def fd_sor_(p, C, dx, dy, beta, tol, max_sweeps):
     nbytes = _lib.lib().nns_fd_sor_workspace(B, nx, ny, p.element_size())
     work = torch.empty(nbytes // p.element_size(), dtype=p.dtype, device=p.device)
     _call('nns_fd_sor', suf, _p(p), _p(C), _p(info), _p(work), B, nx, ny, dx, dy, beta, tol, int(max_sweeps), _stream())
+    return info
+
+
+def fd_sor_redblack_(p, C, dx, dy, beta, tol, max_sweeps):
+    """Red-black SOR, in place on p (an option of the build).  Returns the device info tensor [batch, 2]."""
+    suf, (B, nx, ny) = _chk(p, C)
+    info = torch.empty(B, 2, dtype=p.dtype, device=p.device)
+    _call('nns_fd_sor_redblack', suf, _p(p), _p(C), _p(info), B, nx, ny, dx, dy, beta, tol, int(max_sweeps), _stream())
     return info
 
 

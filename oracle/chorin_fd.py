@@ -52,6 +52,65 @@ def explicit_predictor(u, v, u1, v1, dt, dx, dy, nu):
     return ui, vi
 
 
+def explicit_predictor_corrected(u, v, u1, v1, dt, dx, dy, nu):
+    """SURVEY.md section 8 (f) rank 3, "fixed y-advection": the explicit predictor with v d/dy taken along y
+    (the reference differences along x twice, src/chorin_fd/simulate.py:73-76,:82-85).  An OPTION of the build,
+    not reference behaviour: pinned analytically (tests/test_oracle_golden.py: a field that varies only in y is
+    advected by v, which the reference's form cannot do)."""
+    ui, vi = u.copy(), v.copy()
+    c = (Ellipsis, slice(1, -1), slice(1, -1))
+    xp = (Ellipsis, slice(2, None), slice(1, -1))
+    xm = (Ellipsis, slice(None, -2), slice(1, -1))
+    yp = (Ellipsis, slice(1, -1), slice(2, None))
+    ym = (Ellipsis, slice(1, -1), slice(None, -2))
+
+    def adv(a, b, f):
+        return a[c] * (f[xp] - f[xm]) / (2 * dx) + b[c] * (f[yp] - f[ym]) / (2 * dy)
+
+    def lap(f):
+        return ((f[xp] - 2 * f[c] + f[xm]) / dx**2 + (f[yp] - 2 * f[c] + f[ym]) / dy**2)
+
+    ui[c] = u[c] - dt * (3 / 2. * adv(u, v, u) - 1 / 2. * adv(u1, v1, u1)) + dt * nu * (3 / 2. * lap(u) - 1 / 2. * lap(u1))
+    vi[c] = v[c] - dt * (3 / 2. * adv(u, v, v) - 1 / 2. * adv(u1, v1, v1)) + dt * nu * (3 / 2. * lap(v) - 1 / 2. * lap(v1))
+    return ui, vi
+
+
+def sor_sweep_redblack(p, C, dx, dy, beta):
+    """One red-black SOR sweep (same update formula as :193-196): first the points with (i + j) even, then the odd
+    ones.  Within a colour every update reads only the other colour, so the half-sweep is order-independent --
+    fully parallel, and shardable across GPUs with one halo exchange per half-sweep."""
+    nx, ny = p.shape[-2], p.shape[-1]
+    dx2, dy2 = dx**2, dy**2
+    den = (2 * dx**2 + 2 * dy**2)
+    I, J = np.meshgrid(np.arange(1, nx - 1), np.arange(1, ny - 1), indexing='ij')
+    for colour in (0, 1):
+        m = ((I + J) % 2) == colour
+        i, j = I[m], J[m]
+        p[..., i, j] = (beta * (dy2 * p[..., i + 1, j] + dy2 * p[..., i - 1, j] +
+                                dx2 * p[..., i, j + 1] + dx2 * p[..., i, j - 1] -
+                                C[..., i, j]) / den + (1 - beta) * p[..., i, j])
+    return p
+
+
+def get_pressure_redblack(ui, vi, p, dt, dx, dy, rho, beta, nit, tol=SOR_TOL, return_info=False):
+    """get_pressure with red-black sweeps: same right-hand side, relaxation factor, stopping rule and sweep cap
+    (:184-202); the iterates differ from the lexicographic order (an option, not reference behaviour)."""
+    assert p.ndim == 2
+    err, it = 1, 1
+    pPrev = p.copy()
+    C = pressure_rhs(ui, vi, dt, dx, dy, rho)
+    sweeps = 0
+    while (err > tol) and (it < nit):
+        sor_sweep_redblack(p, C, dx, dy, beta)
+        err = np.max(np.abs(p - pPrev))
+        pPrev = p.copy()
+        it += 1
+        sweeps += 1
+    if return_info:
+        return p, (sweeps, float(err))
+    return p
+
+
 def thomas_const(lo, di, up, rhs):
     """Solve tridiag(lo, di, up) X = rhs along axis -2 of rhs ([..., n, m]) for a constant-
     coefficient tridiagonal matrix.  No pivoting: identical arithmetic to an LU of the dense
@@ -177,17 +236,20 @@ def correction(ui, vi, p, dt, dx, dy):
 
 
 def step(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, dt, dx, dy, rho, nu, beta, nit,
-         method='semi_implicit', return_info=False):
-    """src/chorin_fd/simulate.py:212-234.  ``p`` is mutated (as in the reference)."""
+         method='semi_implicit', return_info=False, advection='reference', pressure_solver='sor'):
+    """src/chorin_fd/simulate.py:212-234.  ``p`` is mutated (as in the reference).  advection / pressure_solver select
+    the build's corrected options (section 8 (f) rank 3); the defaults are the reference."""
     if method == 'explicit':
-        ui, vi = explicit_predictor(un, vn, un1, vn1, dt, dx, dy, nu)
+        pred = explicit_predictor_corrected if advection == 'corrected' else explicit_predictor
+        ui, vi = pred(un, vn, un1, vn1, dt, dx, dy, nu)
     elif method == 'semi_implicit':
         ui, vi = semi_implicit_predictor(un, vn, un1, vn1, dt, dx, dy, nu)
     else:
         raise Exception('method not recognized: {}'.format(method))
     apply_bc_list(ui, u_bc)
     apply_bc_list(vi, v_bc)
-    p, info = get_pressure(ui, vi, p, dt, dx, dy, rho, beta, nit, return_info=True)
+    solve = get_pressure_redblack if pressure_solver == 'redblack' else get_pressure
+    p, info = solve(ui, vi, p, dt, dx, dy, rho, beta, nit, return_info=True)
     apply_bc_list(p, p_bc)
     u_new, v_new = correction(ui, vi, p, dt, dx, dy)
     if return_info:
@@ -195,7 +257,7 @@ def step(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, dt, dx, dy, rho, nu, beta, nit,
     return u_new, v_new, p
 
 
-def simulate(u_ic, v_ic, p_ic, u_bc, v_bc, p_bc, nt, nit, dt, rho, nu, beta, method):
+def simulate(u_ic, v_ic, p_ic, u_bc, v_bc, p_bc, nt, nit, dt, rho, nu, beta, method, advection='reference', pressure_solver='sor'):
     """src/chorin_fd/simulate.py:236-271.  Returns stacked [nt, nx, ny] u, v, p."""
     nx, ny = u_ic.shape
     dx, dy = grid_spacing(nx, ny)
@@ -206,7 +268,8 @@ def simulate(u_ic, v_ic, p_ic, u_bc, v_bc, p_bc, nt, nit, dt, rho, nu, beta, met
     u1, v1 = u.copy(), v.copy()
     us, vs, ps = [], [], []
     for _ in range(nt):
-        _u, _v, p = step(u, v, u1, v1, p, u_bc, v_bc, p_bc, dt, dx, dy, rho, nu, beta, nit, method)
+        _u, _v, p = step(u, v, u1, v1, p, u_bc, v_bc, p_bc, dt, dx, dy, rho, nu, beta, nit, method,
+                         advection=advection, pressure_solver=pressure_solver)
         u1, v1 = u, v
         u, v = _u, _v
         us.append(u.copy()), vs.append(v.copy()), ps.append(p.copy())

@@ -323,3 +323,63 @@ def test_graph_replay_equals_eager_loop(gpu_device):
     ug = d.simulate_device(use_graph=True)[0]
     d2 = DirectNS(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=12, nit=20, nx=n, ny=n, dt=1e-3, rho=1, nu=0.1)
     assert torch.equal(ug, d2.simulate_device(use_graph=False)[0])
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_corrected_options_vs_oracle(gpu_device, dtype):
+    """SURVEY section 8 (f) rank 3 options: the corrected explicit predictor (1e-13 / 1e-5 vs the oracle) and the
+    red-black SOR (bitwise in float64 incl. sweep count; early stop and sweep cap; ragged and batched grids)."""
+    import torch
+    from nns import ops
+    from oracle import chorin_fd as O
+    rng = np.random.default_rng(12)
+    tol = 1e-13 if dtype == "float64" else 2e-5
+    for shape in ((1, 33, 47), (3, 64, 64)):
+        f = [rng.standard_normal(shape).astype(dtype) for _ in range(4)]
+        dt, dx, dy, nu = 1e-3, 0.03, 0.05, 0.1
+        ref = O.explicit_predictor_corrected(*[a.astype(np.float64) for a in f], dt, dx, dy, nu)
+        got = ops.fd_predictor_explicit_corrected(*[torch.as_tensor(a, device="cuda") for a in f], dt, dx, dy, nu)
+        for g, r in zip(got, ref):
+            assert rel_l2(g.cpu().numpy(), r) < tol
+    for (nx, ny), cap, stol in (((20, 17), 30, 5e-6), ((64, 64), 49, 5e-6), ((40, 56), 2000, 1e-4), ((150, 140), 12, 5e-6)):
+        B = 2
+        C = (rng.standard_normal((B, nx, ny)) * 0.1).astype(dtype)
+        p0 = (rng.standard_normal((B, nx, ny)) * 0.01).astype(dtype)
+        dx, dy, beta = 1.0 / nx, 1.0 / ny, 1.5
+        p = torch.as_tensor(p0.copy(), device="cuda")
+        info = ops.fd_sor_redblack_(p, torch.as_tensor(C, device="cuda"), dx, dy, beta, stol, cap).cpu().numpy()
+        for b in range(B):
+            pr = p0[b].copy(); err, sweeps = 1, 0
+            prev = pr.copy()
+            while err > stol and sweeps < cap:
+                O.sor_sweep_redblack(pr, C[b], np.dtype(dtype).type(dx), np.dtype(dtype).type(dy), np.dtype(dtype).type(beta))
+                err = np.max(np.abs(pr - prev)); prev = pr.copy(); sweeps += 1
+            if dtype == "float64":
+                assert int(info[b, 0]) == sweeps, (nx, ny, b)
+                assert np.array_equal(p[b].cpu().numpy(), pr), (nx, ny, b)
+            else:
+                assert abs(int(info[b, 0]) - sweeps) <= 1
+                assert rel_l2(p[b].cpu().numpy(), pr) < 1e-4
+
+
+
+
+def test_cavity_with_corrected_options(gpu_device):
+    """The cavity driver with advection='corrected', pressure_solver='redblack' against the oracle run with the same
+    options (float64, 1e-9); the defaults still reproduce the reference."""
+    from nns.chorin_fd import NavierStokesSystem
+    from oracle import chorin_fd as O
+    from oracle.boundary import cavity_bcs
+    n, nt = 32, 8
+    dx = dy = 2. / (n - 1)
+    u_bc, v_bc, p_bc = cavity_bcs(dx, dy)
+    z = np.zeros((n, n))
+    kw = dict(nt=nt, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.05, beta=1.25, method='explicit')
+    u, v, p = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, advection='corrected', pressure_solver='redblack', **kw).simulate()
+    ur, vr, pr = O.simulate(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt, 50, 1e-3, 1, 0.05, 1.25, 'explicit',
+                            advection='corrected', pressure_solver='redblack')
+    assert np.abs(u - ur).max() < 1e-9 and np.abs(v - vr).max() < 1e-9 and np.abs(p - pr).max() < 1e-9
+    u0, _, _ = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, **kw).simulate()
+    assert np.abs(u0 - u).max() > 1e-6                                  # the options do change the flow
+    with pytest.raises(ValueError):
+        NavierStokesSystem(z, z, z, u_bc, v_bc, p_bc, advection='corrected', **dict(kw, method='semi_implicit'))

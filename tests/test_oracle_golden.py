@@ -171,3 +171,26 @@ def test_chorin_spectral_single_step(N):
     assert rel_l2(ui, g['pred_ui']) < 1e-8 and rel_l2(vi, g['pred_vi']) < 1e-8
     a, b, c = OS.correction_step(S, g['pred_ui'], g['pred_vi'], g['p'], dt, rho)
     assert rel_l2(a, g['corr_u']) < 1e-8 and rel_l2(b, g['corr_v']) < 1e-8 and rel_l2(c, g['corr_p']) < 1e-8
+
+
+def test_corrected_options_known_answers():
+    """SURVEY section 8 (f) rank 3 options.  (1) Corrected explicit predictor: for u = sin(y), v = 1 (uniform in x) the
+    exact advection term v u_y = cos(y) is reproduced to 2nd order, while the reference's form (x-difference twice)
+    gives zero.  (2) Red-black SOR converges to the same discrete Poisson solution as the lexicographic sweep."""
+    from oracle import chorin_fd as O
+    n = 64
+    y = np.linspace(0, 2 * np.pi, n)
+    dx = dy = y[1] - y[0]
+    u = np.tile(np.sin(y)[None, :], (n, 1)); v = np.ones((n, n))
+    dt, nu = 1e-3, 0.0
+    ui_c, _ = O.explicit_predictor_corrected(u, v, u, v, dt, dx, dy, nu)
+    ui_r, _ = O.explicit_predictor(u, v, u, v, dt, dx, dy, nu)
+    adv_c = -(ui_c - u)[1:-1, 1:-1] / dt
+    assert np.abs(adv_c - np.cos(y)[None, 1:-1]).max() < 2e-3            # O(dy^2)
+    assert np.abs((ui_r - u)[1:-1, 1:-1]).max() == 0.0                      # the reference cannot see d/dy
+    rng = np.random.default_rng(0)
+    nx, ny = 24, 20
+    ui, vi = rng.standard_normal((nx, ny)), rng.standard_normal((nx, ny))
+    p1 = O.get_pressure(ui, vi, np.zeros((nx, ny)), 1e-2, 0.1, 0.1, 1.0, 1.5, 5000, tol=1e-13)
+    p2 = O.get_pressure_redblack(ui, vi, np.zeros((nx, ny)), 1e-2, 0.1, 0.1, 1.0, 1.5, 5000, tol=1e-13)
+    assert np.abs(p1 - p2).max() < 1e-9 * max(1.0, np.abs(p1).max())
