@@ -46,6 +46,13 @@ def cfg1():
                 tag = '%s_B%d_%s' % (method, B, 'graph' if graph else 'eager')
                 out[tag + '_ms_per_step'] = 1e3 * dt
                 out[tag + '_pt_steps_per_s'] = B * n * n / dt
+    # the build's corrected options (section 8 (f) rank 3): true y-advection + red-black SOR
+    for B in (1, 256):
+        z = np.zeros((n, n)) if B == 1 else np.zeros((B, n, n))
+        s = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=200, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02,
+                               beta=1.25, method='explicit', advection='corrected', pressure_solver='redblack')
+        dt = timeit(lambda: s.simulate_device(use_graph=False), iters=2, warm=1) / 200
+        out['explicit_corrected_redblack_B%d_eager_ms_per_step' % B] = 1e3 * dt
     return dict(config='cfg1 chorin_fd 64x64 cavity Re=100, nit=50, float64 (reference CPU: 0.51 s/step)', **out)
 
 
