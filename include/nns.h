@@ -173,6 +173,14 @@ int nns_fd_residual_bwd_f64(const double* u, const double* v, const double* g_u,
                             double* grad_u, double* grad_v, double* grad_p, double* grad_u_prev, double* grad_v_prev,
                             int batch, int nx, int ny, double dt, double dx, double dy,
                             double rho, double nu, int stencil, void* stream);
+/* Vector-Jacobian product of the spectral residual (oracle/periodic.py: spectral_residual_vjp): two fused passes like
+ * the forward (columns, then rows), three packed forward (float64 when precise) and three inverse (float32) LDS-resident
+ * transforms per line -- the conjugate spectral multiplies.  grad_u_prev / grad_v_prev may be null.  nx, ny powers of
+ * two in [64, 1024]. */
+int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,
+                              float* grad_u, float* grad_v, float* grad_p, float* grad_u_prev, float* grad_v_prev,
+                              int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
+                              int precise, void* stream);
 /* Spectral back-end: d/dx <-> i kx, lap <-> -|k|^2 via LDS-resident 1-D FFTs (the operators are
  * separable, so no 2-D transform is materialised): pass 1 transforms columns (axis 0) and leaves
  * the x-part of the residual in r_u, r_v, r_div; pass 2 transforms rows (axis 1) and completes

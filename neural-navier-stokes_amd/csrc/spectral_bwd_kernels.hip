@@ -1,0 +1,301 @@
+// Backward (vector-Jacobian product) of the Fourier-spectral residual, gfx950: the conjugate spectral multiplies.
+// Operator definition: oracle/periodic.py (spectral_residual_vjp); SURVEY.md section 8 (f) rank 2.
+//
+// With a = g_u, b = g_v, d = g_div, D^T = -D, L^T = L (see the oracle), the product separates by direction exactly
+// like the forward:
+//   x-pass (columns):  GU = a u_x + b v_x - [D_x(a u + d) + nu L_x a],  GV = -[D_x(b u) + nu L_x b],  GP = -(D_x a)/rho
+//   y-pass (rows):     grad_u = GU + a/dt           - [D_y(a v)     + nu L_y a]
+//                      grad_v = GV + b/dt + a u_y + b v_y - [D_y(b v + d) + nu L_y b]
+//                      grad_p = GP - (D_y b)/rho,   grad_u_prev = -a/dt,  grad_v_prev = -b/dt (optional)
+// Per line three packed forward transforms (float64) and three inverse ones (float32), on the forward's FFT engine:
+//   Z3 = FFT(f + i g)   ->  ifft(i k Z3)            = (f', g')            (f, g) = (u, v)
+//   Z2 = FFT(a + i b)   ->  ifft(i k Z2)            = (a', b')            one component is used per pass
+//   Z1 = FFT(s1 + i s2) ->  ifft(i k Z1 - nu k^2 Z2) = (D s1 + nu L a, D s2 + nu L b)
+// HBM traffic (fp32): x-pass 5 in + 3 out = 32 B/pt, y-pass 8 in + 3..5 out = 44..52 B/pt.
+#include "spectral_common.h"
+
+using namespace nns;
+using namespace nns::spec;
+
+namespace {
+
+struct AdjK {
+    double c1;            // kscale / N
+    double c2;            // nu kscale^2 / N
+    float inv_rho, inv_dt;
+};
+
+// One line.  In: (f, g), (a, b), (s1, s2) as element tid + TPF*m in slot m.  Out: w = a f' + b g', da = a' (USE_A) or b',
+// (cu, cv) = (D s1 + nu L a, D s2 + nu L b).
+template <int N, typename TF, bool USE_A>
+__device__ __forceinline__ void adj_core(const float (&ff)[16], const float (&gf)[16], const float (&af)[16], const float (&bf)[16],
+                                         const float (&s1)[16], const float (&s2)[16],
+                                         float (&w)[16], float (&da)[16], C2<float> (&c)[16],
+                                         const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid, const AdjK& k) {
+    const C2<TF>* tabF2 = tabF + N / 2;
+    const C2<float>* tabI2 = tabI + N / 2;
+    C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);
+    C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
+    C2<TF> z[16];
+    C2<float> e[16];
+    // ---- (f', g')
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)ff[m]; z[m].y = (TF)gf[m]; }
+    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    int te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        int ko, ke;
+        wavenumber<N, m>(te, ko, ke);
+        const TF k1 = (TF)((double)ko * k.c1);
+        e[m].x = (float)(-k1 * z[m].y); e[m].y = (float)(k1 * z[m].x);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true>(e, tabI, tabI2, xbI, tid);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) w[m] = af[m] * e[m].x + bf[m] * e[m].y;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- a', b' and the viscous term  -nu k^2 Z2  (kept in c)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)af[m]; z[m].y = (TF)bf[m]; }
+    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        int ko, ke;
+        wavenumber<N, m>(te, ko, ke);
+        const TF k1 = (TF)((double)ko * k.c1);
+        const TF k2 = (TF)((double)(ke * ke) * k.c2);
+        e[m].x = (float)(-k1 * z[m].y); e[m].y = (float)(k1 * z[m].x);
+        c[m].x = (float)(-k2 * z[m].x); c[m].y = (float)(-k2 * z[m].y);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true>(e, tabI, tabI2, xbI, tid);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) da[m] = USE_A ? e[m].x : e[m].y;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- D s1 + nu L a,  D s2 + nu L b
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)s1[m]; z[m].y = (TF)s2[m]; }
+    fft_line<TF, N, false>(z, tabF, tabF2, xbF, tid);
+    te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        int ko, ke;
+        wavenumber<N, m>(te, ko, ke);
+        const TF k1 = (TF)((double)ko * k.c1);
+        c[m].x += (float)(-k1 * z[m].y); c[m].y += (float)(k1 * z[m].x);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true>(c, tabI, tabI2, xbI, tid);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// y-pass: rows.  One line per TPF lanes; grid-stride over all batch*nx rows.  gu, gv, gp hold the x-pass partials on
+// entry and the gradients on exit.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N, typename TF>
+__global__ __launch_bounds__(kSpecThreads) void spec_bwd_ypass_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                       const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gd,
+                                                                       float* __restrict__ gu, float* __restrict__ gv, float* __restrict__ gp,
+                                                                       float* __restrict__ gup, float* __restrict__ gvp, long nrows, AdjK k) {
+    using L = SpecLds<N, TF>;
+    constexpr int TPF = L::TPF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, TF>(smem, tabF, tabI, lines);
+    const long niter = (nrows + L::LINES - 1) / L::LINES;
+    for (long it = blockIdx.x; it < niter; it += gridDim.x) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        const int line = wave * L::FPW + sub;
+        unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
+        const long row_raw = it * L::LINES + line;
+        const bool valid = row_raw < nrows;
+        const long row = valid ? row_raw : nrows - 1;
+        int tidv = tid;
+        asm volatile("" : "+v"(tidv));
+        const size_t base = (size_t)row * N + tidv;
+        float vf[16], af[16], bf[16], s1[16], s2[16], w[16], db[16];
+        C2<float> c[16];
+        {
+            float uf[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const size_t q = base + TPF * m;
+                uf[m] = u[q]; vf[m] = v[q]; af[m] = ga[q]; bf[m] = gb[q]; s2[m] = gd[q];
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { s1[m] = af[m] * vf[m]; s2[m] = bf[m] * vf[m] + s2[m]; }      // a v,  b v + d
+            adj_core<N, TF, false>(uf, vf, af, bf, s1, s2, w, db, c, tabF, tabI, xb, tidv, k);
+        }
+        // epilogue in two halves: partials in, gradients out
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float pu[8], pv[8], pp[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const size_t q = base + TPF * (8 * h + i); pu[i] = gu[q]; pv[i] = gv[q]; pp[i] = gp[q]; }
+            if (valid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = 8 * h + i;
+                    const size_t q = base + TPF * m;
+                    gu[q] = pu[i] + af[m] * k.inv_dt - c[m].x;
+                    gv[q] = pv[i] + bf[m] * k.inv_dt + w[m] - c[m].y;
+                    gp[q] = pp[i] - db[m] * k.inv_rho;
+                    if (gup) gup[q] = -af[m] * k.inv_dt;
+                    if (gvp) gvp[q] = -bf[m] * k.inv_dt;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// x-pass: columns.  A workgroup owns LINES adjacent columns of one grid; the five input fields go through the LDS
+// transpose stage in two rounds (u, v, a then b, d: the stage holds three fields), the three partials come back in one.
+// ------------------------------------------------------------------------------------------------------------------
+template <int N, typename TF>
+__global__ __launch_bounds__(kSpecThreads) void spec_bwd_xpass_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                       const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gd,
+                                                                       float* __restrict__ gu, float* __restrict__ gv, float* __restrict__ gp,
+                                                                       int ny, int tiles_per_grid, long ntiles, AdjK k) {
+    using L = SpecLds<N, TF>;
+    constexpr int TPF = L::TPF, CW = L::LINES, SF = L::STAGE_F;
+    constexpr int ROWS_PER_IT = kSpecThreads / CW;
+    constexpr int NR = N / ROWS_PER_IT;
+    static_assert(NR == 16, "staging geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, TF>(smem, tabF, tabI, lines);
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        const int line = wave * L::FPW + sub;
+        unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
+        float* my_stage = reinterpret_cast<float*>(xb) + (line % L::SKEW_MOD) * L::SKEW_DW;
+        const long lt = xcd_remap((unsigned)t, (unsigned)ntiles);
+        const int j0 = (int)(lt % tiles_per_grid) * CW;
+        const size_t g = (size_t)(lt / tiles_per_grid) * N * ny;
+        const int cc = tx % CW, cr = tx / CW;
+        const int col = j0 + cc < ny ? j0 + cc : ny - 1;                               // clamped: loads need no mask
+        float* cp_stage = reinterpret_cast<float*>(lines + (size_t)cc * L::LINE_BYTES) + (cc % L::SKEW_MOD) * L::SKEW_DW;
+        int tidv = tid;
+        asm volatile("" : "+v"(tidv));
+        float uf[16], vf[16], af[16], bf[16], s1[16];
+        // round 1: u, v, a
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = cr + ROWS_PER_IT * i;
+            const size_t q = g + (size_t)r * ny + col;
+            cp_stage[0 * SF + r] = u[q]; cp_stage[1 * SF + r] = v[q]; cp_stage[2 * SF + r] = ga[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            uf[m] = my_stage[0 * SF + tidv + TPF * m]; vf[m] = my_stage[1 * SF + tidv + TPF * m]; af[m] = my_stage[2 * SF + tidv + TPF * m];
+        }
+        __syncthreads();
+        // round 2: b, d
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = cr + ROWS_PER_IT * i;
+            const size_t q = g + (size_t)r * ny + col;
+            cp_stage[0 * SF + r] = gb[q]; cp_stage[1 * SF + r] = gd[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { bf[m] = my_stage[0 * SF + tidv + TPF * m]; s1[m] = my_stage[1 * SF + tidv + TPF * m]; }
+        __syncthreads();                                                               // the stage aliases the exchange image
+        float s2[16], w[16], dax[16];
+        C2<float> c[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { s1[m] = af[m] * uf[m] + s1[m]; s2[m] = bf[m] * uf[m]; }           // a u + d,  b u
+        adj_core<N, TF, true>(uf, vf, af, bf, s1, s2, w, dax, c, tabF, tabI, xb, tidv, k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            my_stage[0 * SF + tidv + TPF * m] = w[m] - c[m].x;                        // GU
+            my_stage[1 * SF + tidv + TPF * m] = -c[m].y;                              // GV
+            my_stage[2 * SF + tidv + TPF * m] = -dax[m] * k.inv_rho;                  // GP
+        }
+        __syncthreads();
+        if (j0 + cc < ny) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = cr + ROWS_PER_IT * i;
+                const size_t q = g + (size_t)r * ny + j0 + cc;
+                gu[q] = cp_stage[0 * SF + r]; gv[q] = cp_stage[1 * SF + r]; gp[q] = cp_stage[2 * SF + r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int N, typename TF>
+int launch_bwd(const float* u, const float* v, const float* ga, const float* gb, const float* gd, float* gu, float* gv, float* gp,
+               float* gup, float* gvp, int batch, int nx_or_ny_other, bool xpass, const AdjK& k, hipStream_t s) {
+    using L = SpecLds<N, TF>;
+    const long gmax = spec_grid_cap();
+    if (xpass) {
+        auto kern = spec_bwd_xpass_kernel<N, TF>;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec bwd xpass: hipFuncSetAttribute(%d B): %s", L::TOTAL, hipGetErrorString(e));
+            attr = true;
+        }
+        const int ny = nx_or_ny_other;
+        const int tiles_per_grid = (ny + L::LINES - 1) / L::LINES;
+        const long ntiles = (long)batch * tiles_per_grid;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < gmax ? ntiles : gmax)), dim3(kSpecThreads), L::TOTAL, s, u, v, ga, gb, gd, gu, gv, gp, ny, tiles_per_grid, ntiles, k);
+        return check_launch("spec_residual_bwd_xpass");
+    }
+    auto kern = spec_bwd_ypass_kernel<N, TF>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec bwd ypass: hipFuncSetAttribute(%d B): %s", L::TOTAL, hipGetErrorString(e));
+        attr = true;
+    }
+    const long nrows = (long)batch * nx_or_ny_other;
+    const long niter = (nrows + L::LINES - 1) / L::LINES;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(niter < gmax ? niter : gmax)), dim3(kSpecThreads), L::TOTAL, s, u, v, ga, gb, gd, gu, gv, gp, gup, gvp, nrows, k);
+    return check_launch("spec_residual_bwd_ypass");
+}
+
+}  // namespace
+
+NNS_API int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,
+                                      float* grad_u, float* grad_v, float* grad_p, float* grad_u_prev, float* grad_v_prev,
+                                      int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu, int precise, void* stream) {
+    if (!u || !v || !g_u || !g_v || !g_div || !grad_u || !grad_v || !grad_p || batch < 1)
+        return fail(NNS_ERR_INVALID_ARG, "spec_residual_bwd: bad args");
+    if (!pow2_in_range(nx) || !pow2_in_range(ny))
+        return fail(NNS_ERR_UNSUPPORTED, "spec_residual_bwd: nx=%d, ny=%d must be powers of two in [64, 1024]", nx, ny);
+    if (Lx == 0 || Ly == 0 || rho == 0 || dt == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_bwd: Lx, Ly, rho, dt must be non-zero");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const double kx = 2.0 * M_PI / Lx, ky = 2.0 * M_PI / Ly;
+    const AdjK kxp{kx / nx, nu * kx * kx / nx, (float)(1.0 / rho), (float)(1.0 / dt)};
+    const AdjK kyp{ky / ny, nu * ky * ky / ny, (float)(1.0 / rho), (float)(1.0 / dt)};
+    int rc = dispatch_n(nx, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        return precise ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s)
+                       : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s);
+    });
+    if (rc) return rc;
+    return dispatch_n(ny, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        return precise ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s)
+                       : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s);
+    });
+}

@@ -1,0 +1,93 @@
+// Scaffolding shared by the spectral residual kernels (forward: spectral_kernels.hip, backward:
+// spectral_bwd_kernels.hip): launch geometry, LDS layout, wavenumber helper, table setup, size dispatch.
+#pragma once
+#include "nns_common.h"
+#include "fft_lds.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace nns {
+namespace spec {
+
+#ifndef NNS_SPEC_THREADS
+#define NNS_SPEC_THREADS 512
+#endif
+constexpr int kSpecThreads = NNS_SPEC_THREADS;      // 8 waves: 2 per SIMD, <= 256 VGPRs each
+constexpr int kSpecWaves = kSpecThreads / kWave;
+
+struct SpecK {
+    // folded on the host (kscale = 2 pi / L of the transformed axis, 1/N = the inverse transform's normalisation):
+    double c1;            // kscale / N            : first-derivative factor per unit wavenumber index
+    double cs;            // kscale / (rho N)      : pressure-gradient factor per unit wavenumber index
+    double c2;            // nu kscale^2 / N       : viscous factor per unit SQUARED wavenumber index
+    float inv_dt;
+};
+
+template <int N, typename TF>
+struct SpecLds {
+    static constexpr int TPF = N / 16;
+    static constexpr int FPW = kWave / TPF;                       // lines per wave
+    static constexpr int LINES = kSpecWaves * FPW;                // lines per workgroup
+    static constexpr int SLOTS = N + N / 16;
+    static constexpr int STAGE_F = N + 16;                        // floats per staged field (padded)
+    static constexpr int XB_BYTES = SLOTS * (int)sizeof(C2<TF>);
+    static constexpr int SKEW_MOD = LINES < 32 ? LINES : 32;           // staging skew: line%SKEW_MOD * SKEW_DW dwords,
+    static constexpr int SKEW_DW = 32 / SKEW_MOD;                       // so a 32-lane store group hits 32 banks
+    static constexpr int STAGE_BYTES = 3 * STAGE_F * 4 + 128;
+    static constexpr int LINE_BYTES = ((XB_BYTES > STAGE_BYTES ? XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
+    static constexpr int TABF_BYTES = (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<TF>);     // main half table + pass-2 table
+    static constexpr int TABI_BYTES = sizeof(TF) == 4 ? 0 : (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<float>);
+    static constexpr int TOTAL = TABF_BYTES + TABI_BYTES + LINES * LINE_BYTES;
+};
+
+// Signed wavenumber index of the element in register slot m of lane `te` (element te + TPF m).  N/2 = 8 TPF, so
+// slots 0..7 hold the non-negative wavenumbers and 8..15 the negative ones: no compare except for the Nyquist mode
+// (slot 8 of lane 0), which odd derivatives drop, as in the oracle.
+template <int N, int M>
+__device__ __forceinline__ void wavenumber(int te, int& k_odd, int& k_even) {
+    constexpr int TPF = N / 16;
+    k_even = te + TPF * M - (M >= 8 ? N : 0);
+    if constexpr (M == 8) k_odd = te == 0 ? 0 : k_even; else k_odd = k_even;
+}
+
+template <int N, typename TF>
+__device__ __forceinline__ void spec_setup(unsigned char* smem, C2<TF>*& tabF, C2<float>*& tabI, unsigned char*& lines) {
+    using L = SpecLds<N, TF>;
+    tabF = reinterpret_cast<C2<TF>*>(smem);
+    fill_twiddles<TF, N>(tabF, threadIdx.x, kSpecThreads);
+    fill_twiddles2<TF, N>(tabF + N / 2, threadIdx.x, kSpecThreads);
+    if constexpr (sizeof(TF) == 4) {
+        tabI = reinterpret_cast<C2<float>*>(smem);
+    } else {
+        tabI = reinterpret_cast<C2<float>*>(smem + L::TABF_BYTES);
+        fill_twiddles<float, N>(tabI, threadIdx.x, kSpecThreads);
+        fill_twiddles2<float, N>(tabI + N / 2, threadIdx.x, kSpecThreads);
+    }
+    lines = smem + L::TABF_BYTES + L::TABI_BYTES;
+    __syncthreads();
+}
+
+// workgroups per launch (grid-stride over tiles): 2 generations per CU -- each generation pays the twiddle-table
+// setup and one exposed first-tile load (2048 cost the x-pass 6 %, same-box sweep); NNS_SPEC_GRID overrides it for tuning
+inline long spec_grid_cap() {
+    static const long cap = [] { const char* e = getenv("NNS_SPEC_GRID"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
+    return cap;
+}
+
+inline bool pow2_in_range(int n) { return n >= 64 && n <= 1024 && (n & (n - 1)) == 0; }
+
+template <typename F>
+int dispatch_n(int n, F&& f) {
+    switch (n) {
+        case 64: return f(std::integral_constant<int, 64>{});
+        case 128: return f(std::integral_constant<int, 128>{});
+        case 256: return f(std::integral_constant<int, 256>{});
+        case 512: return f(std::integral_constant<int, 512>{});
+        case 1024: return f(std::integral_constant<int, 1024>{});
+    }
+    return fail(NNS_ERR_UNSUPPORTED, "spectral: axis length %d is not a power of two in [64, 1024]", n);
+}
+
+
+}  // namespace spec
+}  // namespace nns

@@ -439,9 +439,22 @@ def spec_derivs(f, Lx, Ly, want=('x', 'y', 'lap'), precise=True):
 
 
 def spec_residual_bwd(u, v, g_u, g_v, g_div, dt, Lx, Ly, rho, nu, precise=True, want_prev=True):
-    """Vector-Jacobian product of spec_residual (oracle/periodic.py: spectral_residual_vjp).  First version: the adjoint
-    operators (D^T = -D, L^T = L) are applied by the HIP spectral-derivative kernel (nns_spec_derivs_f32, 8 launches)
-    and combined with elementwise tensor ops; a fused two-pass kernel like the forward's is the planned replacement."""
+    """Vector-Jacobian product of spec_residual (oracle/periodic.py: spectral_residual_vjp) by the fused two-pass
+    backward kernels (nns_spec_residual_bwd_f32): returns (grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev)."""
+    suf, (B, nx, ny) = _chk(u, v, g_u, g_v, g_div)
+    if suf != '_f32':
+        raise TypeError("spec_residual_bwd: float32 fields")
+    gu, gv, gp = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    gup, gvp = (torch.empty_like(u), torch.empty_like(u)) if want_prev else (None, None)
+    check(_lib.lib().nns_spec_residual_bwd_f32(_p(u), _p(v), _p(g_u), _p(g_v), _p(g_div), _p(gu), _p(gv), _p(gp),
+                                               _p(gup) if want_prev else None, _p(gvp) if want_prev else None,
+                                               B, nx, ny, dt, Lx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_bwd_f32')
+    return gu, gv, gp, gup, gvp
+
+
+def spec_residual_bwd_composed(u, v, g_u, g_v, g_div, dt, Lx, Ly, rho, nu, precise=True):
+    """The same product assembled from the standalone spectral-derivative kernel (8 launches) and elementwise tensor
+    ops: kept as an independent cross-check of the fused kernels (tests), not used on the training path."""
     _f32(u, v, g_u, g_v, g_div)
     d = lambda f, *want: spec_derivs(f.contiguous(), Lx, Ly, want, precise)
     du, dv = d(u, 'x', 'y'), d(v, 'x', 'y')
@@ -449,7 +462,7 @@ def spec_residual_bwd(u, v, g_u, g_v, g_div, dt, Lx, Ly, rho, nu, precise=True, 
     grad_u = g_u / dt + g_u * du['x'] + g_v * dv['x'] - d(g_u * u + g_div, 'x')['x'] - d(g_u * v, 'y')['y'] - nu * da['lap']
     grad_v = g_v / dt + g_u * du['y'] + g_v * dv['y'] - d(g_v * u, 'x')['x'] - d(g_v * v + g_div, 'y')['y'] - nu * db['lap']
     grad_p = -(da['x'] + db['y']) / rho
-    return grad_u, grad_v, grad_p, (-g_u / dt if want_prev else None), (-g_v / dt if want_prev else None)
+    return grad_u, grad_v, grad_p
 
 
 class SpecResidualFn(torch.autograd.Function):

@@ -256,7 +256,7 @@ def test_physics_loss_autograd(gpu_device):
         assert rel_l2(tt.grad.cpu().numpy(), rr) < 1e-11
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 256, 64)])
+@pytest.mark.parametrize("shape", [(2, 64, 128), (1, 256, 64), (1, 1024, 512), (3, 512, 1024)])
 def test_spectral_residual_backward_vs_oracle(gpu_device, shape):
     """VJP of the spectral residual (adjoint operators applied by the HIP spectral engine) vs the oracle, 1e-5; and
     through autograd on band-limited fields."""
@@ -278,6 +278,11 @@ def test_spectral_residual_backward_vs_oracle(gpu_device, shape):
     got = ops.spec_residual_bwd(*[torch.as_tensor(a, device='cuda') for a in f], dt, Lx, Ly, rho, nu)
     for name, g, r in zip(('u', 'v', 'p', 'u_prev', 'v_prev'), got, ref):
         assert rel_l2(g.cpu().numpy(), r) < 1e-5, (name, shape)
+    comp = ops.spec_residual_bwd_composed(*[torch.as_tensor(a, device='cuda') for a in f], dt, Lx, Ly, rho, nu)
+    for g, r in zip(comp, ref):                                  # the independent composition agrees too
+        assert rel_l2(g.cpu().numpy(), r) < 1e-5
+    no_prev = ops.spec_residual_bwd(*[torch.as_tensor(a, device='cuda') for a in f], dt, Lx, Ly, rho, nu, want_prev=False)
+    assert no_prev[3] is None and rel_l2(no_prev[0].cpu().numpy(), ref[0]) < 1e-5
     eng = ResidualEngine(nx, ny, dt, rho, nu, Lx, Ly, backend='spectral')
     t = [torch.as_tensor(a, device='cuda').requires_grad_(True) for a in f]
     loss = eng.physics_loss(*t)
