@@ -35,9 +35,16 @@ def physics_informed_loss(model, engine, state, target=None, lam=1.0, w_div=1.0)
     return data + lam * phys, data, phys
 
 
-def train_step(model, engine, optimizer, state, target=None, lam=1.0, w_div=1.0):
-    optimizer.zero_grad(set_to_none=True)
+def train_step(model, engine, optimizer, state, target=None, lam=1.0, w_div=1.0, bucket=None):
+    """One optimiser step.  Data-parallel runs pass `bucket` (nns.data_parallel.FlatGradAllReduce over the model's
+    parameters): each rank works on its shard of the batch and the gradients are averaged with ONE all-reduce."""
+    if bucket is not None:
+        bucket.zero_()
+    else:
+        optimizer.zero_grad(set_to_none=True)
     total, data, phys = physics_informed_loss(model, engine, state, target, lam, w_div)
     total.backward()
+    if bucket is not None:
+        bucket.reduce_()
     optimizer.step()
     return total.detach(), data.detach(), phys.detach()
