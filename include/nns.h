@@ -252,9 +252,10 @@ int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const float* bia
 
 /* Its backward (what autograd would do for the reference's Conv2d/ReLU stack, spectral_ode.py:100-119), fused in one
  * launch that recomputes the forward in registers: gy [mb, widths[nlayers], P] -> gx [mb, widths[0], P], gW / gB packed
- * like weights / biases (overwritten).  bf16 mode only (bf16 == 0: NNS_ERR_UNSUPPORTED): operands rounded to bfloat16
- * exactly as the forward does, float32 accumulation; weight gradients contract over pixels with transposing LDS reads
- * and are reduced over workgroups in a fixed order.  workspace: nns_pixel_mlp_bwd_workspace bytes of device memory. */
+ * like weights / biases (overwritten).  bf16 != 0: operands rounded to bfloat16 exactly as the forward does, float32
+ * accumulation, any supported shape; bf16 == 0: float32 operands (v_mfma_f32_32x32x2_f32), widths <= 32 only (wider:
+ * NNS_ERR_UNSUPPORTED).  Weight gradients contract over pixels through LDS images and are reduced over workgroups in a
+ * fixed order.  workspace: nns_pixel_mlp_bwd_workspace bytes of device memory. */
 int nns_pixel_mlp_bwd_workspace(const int* widths_host, int nlayers, size_t* bytes);
 int nns_pixel_mlp_bwd_f32(const float* x, const float* gy, const float* weights, const float* biases,
                           float* gx, float* gW, float* gB, int mb, int P, const int* widths_host, int nlayers, int bf16,

@@ -654,6 +654,147 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// float32-operand backward (widths <= 32: e.g. BASELINE config 2's depth-4 width-32 stack), v_mfma_f32_32x32x2_f32.
+// Same structure as the bf16 kernel with OT = 1, but nothing is rounded: the accumulator registers ARE the next
+// product's B operand (k-step i of a 32x32x2 MFMA takes channels {c(i), c(i) + 4}, c(i) = (i&3) + 8 (i>>2), i.e. exactly
+// register i of the two lane halves), each layer's input is kept as its 16 accumulator registers, and because a lane
+// supplies ONE element per MFMA the pixel-contraction operands are plain 4-byte LDS reads (no transpose instruction).
+// The single 32x32 gW block's K range (128 pixels) is split over the four waves.
+// ------------------------------------------------------------------------------------------------------------------
+struct BwdLdsF32 {
+    static constexpr int CH = 32;
+    static constexpr int ROWF = CH + 1;                       // floats per row: +1 keeps column reads conflict-free
+    static constexpr int W_BYTES = CH * ROWF * 4;
+    static constexpr int B_BYTES = CH * 4;
+    static constexpr int IMG_BYTES = 128 * ROWF * 4;
+    __host__ __device__ static int total(int nl) { return nl * (W_BYTES + B_BYTES) + 2 * IMG_BYTES; }
+};
+
+template <bool SMALLIO>
+__global__ __launch_bounds__(256) void pixel_mlp_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                 const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                 float* __restrict__ gx, float* __restrict__ ws,
+                                                                 long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
+    using U = BwdLdsF32;
+    constexpr int ROWF = U::ROWF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nl = d.nlayers;
+    for (int e = threadIdx.x; e < U::total(nl) / 4; e += 256) reinterpret_cast<float*>(lds)[e] = 0.f;
+    __syncthreads();
+    for (int l = 0; l < nl; ++l) {
+        const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
+        const float* Wl = W + d.woff[l];
+        float* dst = reinterpret_cast<float*>(lds + l * U::W_BYTES);
+        for (int e = threadIdx.x; e < n; e += 256) dst[(e / cin) * ROWF + e % cin] = Wl[e];
+        float* bl = reinterpret_cast<float*>(lds + nl * U::W_BYTES + l * U::B_BYTES);
+        for (int e = threadIdx.x; e < cout; e += 256) bl[e] = Bv[d.boff[l] + e];
+    }
+    __syncthreads();
+    const unsigned char* bias0 = lds + nl * U::W_BYTES;
+    float* imgD = reinterpret_cast<float*>(lds + nl * (U::W_BYTES + U::B_BYTES));
+    float* imgA = imgD + 128 * ROWF;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
+    const int cin0 = d.cin[0], coutL = d.cout[nl - 1];
+    f32x16 gw[kMaxLayers];
+    float gbp[kMaxLayers];
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        gbp[l] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gw[l][i] = 0.f;
+    }
+    const long nsuper = (npix_total + 127) / 128;
+    for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+        const long gp = sup * 128 + wave * 32 + r;
+        const bool ok = gp < npix_total;
+        const long gc = ok ? gp : npix_total - 1;
+        const long b = gc / P, p = gc % P;
+        // ---------------- forward: ain[l] = input of layer l as accumulator-layout registers
+        f32x16 ain[kMaxLayers];
+        {
+            f32x16 t[1];
+            load_acc<1, SMALLIO>(x + (size_t)b * cin0 * P + p, (size_t)P, cin0, ok, h, t);
+            ain[0] = t[0];
+        }
+#pragma unroll
+        for (int l = 0; l + 1 < kMaxLayers; ++l) {
+            if (l + 1 < nl) {
+                __builtin_amdgcn_sched_barrier(0);
+                const float* wimg = reinterpret_cast<const float*>(lds + l * U::W_BYTES);
+                const float* bl = reinterpret_cast<const float*>(bias0 + l * U::B_BYTES);
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = bl[acc_row(i, h)];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wimg[r * ROWF + acc_row(i, h)], ain[l][i], acc, 0, 0, 0);     // A = W[out r][in c(i) + 4h]
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ain[l + 1][i] = fmaxf(acc[i], 0.f);
+            }
+        }
+        // ---------------- backward
+        f32x16 dl;
+        {
+            f32x16 t[1];
+            load_acc<1, SMALLIO>(gy + (size_t)b * coutL * P + p, (size_t)P, coutL, ok, h, t);
+            dl = t[0];
+        }
+#pragma unroll
+        for (int l = kMaxLayers - 1; l >= 0; --l) {
+            if (l < nl) {
+                __builtin_amdgcn_sched_barrier(0);
+                const float* wimg = reinterpret_cast<const float*>(lds + l * U::W_BYTES);
+                f32x16 nd;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) nd[i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    nd = __builtin_amdgcn_mfma_f32_32x32x2f32(wimg[acc_row(i, h) * ROWF + r], dl[i], nd, 0, 0, 0);           // A = W^T[in r][out c(i) + 4h]
+                __builtin_amdgcn_sched_barrier(0);
+                {   // delta_l and a_{l-1} as rows [32 wave + r] of the [pix][ch] images (register i = channel c(i) + 4h)
+                    float* rowD = imgD + (32 * wave + r) * ROWF;
+                    float* rowA = imgA + (32 * wave + r) * ROWF;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { rowD[acc_row(i, h)] = dl[i]; rowA[acc_row(i, h)] = ain[l][i]; }
+                }
+                __syncthreads();
+                // this wave's share of the pixel contraction: pixels 32 wave .. 32 wave + 31, two per MFMA
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int pix = 32 * wave + 2 * kk + h;
+                    const float fa = imgD[pix * ROWF + r], fb = imgA[pix * ROWF + r];
+                    gw[l] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, gw[l], 0, 0, 0);
+                    gbp[l] += fa;
+                }
+                __syncthreads();
+                if (l > 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dl[i] = ain[l][i] > 0.f ? nd[i] : 0.f;
+                } else if (ok) {
+                    f32x16 t[1]; t[0] = nd;
+                    store_acc<1, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, t);
+                }
+            }
+        }
+    }
+    // per-wave workspace slices (the block's K range is split over the waves)
+    float* wsb = ws + (size_t)(blockIdx.x * 4 + wave) * nparams;
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        if (l < nl) {
+            const int cin = d.cin[l], cout = d.cout[l];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int out = acc_row(i, h);
+                if (out < cout && r < cin) wsb[d.woff[l] + out * cin + r] = gw[l][i];
+            }
+            const float tot = gbp[l] + __shfl_xor(gbp[l], 32);
+            if (h == 0 && r < cout) wsb[nparams_w + d.boff[l] + r] = tot;
+        }
+    }
+}
+
 __global__ void pixel_mlp_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gB, int nslices, int nparams_w, int nparams) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nparams) return;
@@ -679,6 +820,20 @@ int build_bwd_desc(const int* widths_host, int nlayers, PixelMlpDesc& d, int& np
     }
     nparams_w = woff; nparams = woff + boff;
     return NNS_OK;
+}
+
+template <bool SMALLIO>
+int launch_bwd_f32(const float* x, const float* gy, const float* weights, const float* biases, float* gx, float* gW, float* gB,
+                   long npix, int P, const PixelMlpDesc& d, int nparams_w, int nparams, float* ws, hipStream_t s) {
+    const int lds = BwdLdsF32::total(d.nlayers);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_f32_kernel<SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+    const long nsuper = (npix + 127) / 128;
+    const int blocks = (int)(nsuper < kBwdMaxBlocks ? nsuper : kBwdMaxBlocks);
+    hipLaunchKernelGGL((pixel_mlp_bwd_f32_kernel<SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
+    if (int rc = check_launch("pixel_mlp_bwd")) return rc;
+    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((nparams + 255) / 256), dim3(256), 0, s, ws, gW, gB, blocks * 4, nparams_w, nparams);
+    return check_launch("pixel_mlp_reduce");
 }
 
 template <int OT, bool SMALLIO>
@@ -742,9 +897,9 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
     return check_launch("pixel_mlp_fwd");
 }
 
-// Backward of nns_pixel_mlp_fwd_f32 in its bf16 mode (see the kernel comment).  gy [mb, C_out, P] in; gx [mb, C_in, P],
-// gW (packed like weights) and gB (packed like biases) out -- overwritten, not accumulated.  The float32-operand mode has
-// no backward yet: bf16 == 0 fails with NNS_ERR_UNSUPPORTED.
+// Backward of nns_pixel_mlp_fwd_f32 (see the kernel comments).  gy [mb, C_out, P] in; gx [mb, C_in, P], gW (packed like
+// weights) and gB (packed like biases) out -- overwritten, not accumulated.  bf16 != 0: bf16 operands, any supported shape;
+// bf16 == 0: float32 operands, widths <= 32 (wider stacks fail with NNS_ERR_UNSUPPORTED).
 NNS_API int nns_pixel_mlp_bwd_workspace(const int* widths_host, int nlayers, size_t* bytes) {
     if (!widths_host || !bytes) return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd_workspace: bad args");
     PixelMlpDesc d; int nw, np, maxw;
@@ -758,15 +913,18 @@ NNS_API int nns_pixel_mlp_bwd_f32(const float* x, const float* gy, const float* 
                                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !gy || !weights || !biases || !gx || !gW || !gB || !widths_host || !workspace || mb < 1 || P < 1)
         return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: bad args");
-    if (!bf16) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: only the bf16 mode has a backward kernel");
     PixelMlpDesc d; int nw, np, maxw;
     if (int rc = build_bwd_desc(widths_host, nlayers, d, nw, np, maxw)) return rc;
+    if (!bf16 && maxw > 32) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: the float32-operand backward supports widths <= 32 (got %d); use bf16", maxw);
     if (workspace_bytes < (size_t)kBwdMaxBlocks * (maxw <= 32 ? 4 : 1) * np * sizeof(float))
         return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: workspace too small (%zu B, see nns_pixel_mlp_bwd_workspace)", workspace_bytes);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long npix = (long)mb * P;
     float* ws = static_cast<float*>(workspace);
     const bool small = widths_host[0] <= 4 && widths_host[nlayers] <= 4;
+    if (!bf16)
+        return small ? launch_bwd_f32<true>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s)
+                     : launch_bwd_f32<false>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s);
     if (maxw <= 32)
         return small ? launch_bwd_uniform<1, true>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s)
                      : launch_bwd_uniform<1, false>(x, gy, weights, biases, gx, gW, gB, npix, P, d, nw, np, ws, s);

@@ -176,10 +176,10 @@ class PixelMLP(nn.Module):
         with torch.no_grad():
             return ops.pixel_mlp_fwd(grid.contiguous(), list(self.weights), list(self.biases), bf16=bf16)
 
-    def train_forward(self, grid):
-        """bf16-operand forward recorded as ONE autograd node whose backward is the fused HIP kernel
-        (nns_pixel_mlp_bwd_f32: forward recomputed in registers, no saved activations)."""
-        return ops.PixelMlpFn.apply(grid.contiguous(), len(self.weights), *self.weights, *self.biases)
+    def train_forward(self, grid, bf16=True):
+        """Forward recorded as ONE autograd node whose backward is the fused HIP kernel (nns_pixel_mlp_bwd_f32: forward
+        recomputed in registers, no saved activations).  bf16=False: float32 operands, widths <= 32."""
+        return ops.PixelMlpFn.apply(grid.contiguous(), len(self.weights), bool(bf16), *self.weights, *self.biases)
 
 
 class AverageMeter(object):

@@ -386,7 +386,8 @@ def _pixel_mlp_pack(x, weights, biases, what):
 
 
 def pixel_mlp_bwd(x, gy, weights, biases, bf16=True):
-    """Backward of pixel_mlp_fwd (bf16 mode): returns (gx like x, [gW_l like weights[l]], [gb_l like biases[l]])."""
+    """Backward of pixel_mlp_fwd: returns (gx like x, [gW_l like weights[l]], [gb_l like biases[l]]).
+    bf16=False (float32 operands) supports widths <= 32."""
     import ctypes
     mb, P, ws, widths, wp, bp = _pixel_mlp_pack(x, weights, biases, 'pixel_mlp_bwd')
     _f32(gy)
@@ -409,21 +410,21 @@ def pixel_mlp_bwd(x, gy, weights, biases, bf16=True):
 
 
 class PixelMlpFn(torch.autograd.Function):
-    """pixel_mlp_fwd / pixel_mlp_bwd as one autograd node (bf16 operands, float32 accumulation)."""
+    """pixel_mlp_fwd / pixel_mlp_bwd as one autograd node (bf16 or float32 operands, float32 accumulation)."""
 
     @staticmethod
-    def forward(ctx, x, nlayers, *params):
+    def forward(ctx, x, nlayers, bf16, *params):
         weights, biases = params[:nlayers], params[nlayers:]
-        ctx.nlayers = nlayers
+        ctx.nlayers, ctx.bf16 = nlayers, bool(bf16)
         ctx.save_for_backward(x, *params)
-        return pixel_mlp_fwd(x, weights, biases, bf16=True)
+        return pixel_mlp_fwd(x, weights, biases, bf16=bf16)
 
     @staticmethod
     def backward(ctx, gy):
         x, *params = ctx.saved_tensors
         weights, biases = params[:ctx.nlayers], params[ctx.nlayers:]
-        gx, gws, gbs = pixel_mlp_bwd(x.contiguous(), gy.contiguous(), weights, biases, bf16=True)
-        return (gx, None) + tuple(gws) + tuple(gbs)
+        gx, gws, gbs = pixel_mlp_bwd(x.contiguous(), gy.contiguous(), weights, biases, bf16=ctx.bf16)
+        return (gx, None, None) + tuple(gws) + tuple(gbs)
 
 
 # ----------------------------------------------------------------------------- standalone spectral operators

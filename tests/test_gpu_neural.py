@@ -243,5 +243,33 @@ def test_pixel_mlp_backward_random_and_autograd(gpu_device):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_pixel_mlp_backward_float32(gpu_device):
+    """The float32-operand backward (widths <= 32, BASELINE config 2's depth-4 width-32 stack): 2e-5 against the
+    UNROUNDED float64 oracle, ragged pixel counts and non-(u, v, p) channel counts, autograd; wider stacks fail loudly."""
+    from nns import ops
+    from nns.neural_spectral.spectral_ode import PixelMLP
+    from oracle import neural as ON
+    torch.manual_seed(9)
+    for dims, shape in (([3, 32, 32, 32, 3], (2, 64, 64)), ([3, 16, 32, 32, 16, 3], (2, 8, 8)), ([5, 24, 7], (3, 9, 5)), ([3, 3], (1, 4, 4))):
+        L = len(dims) - 1
+        Ws = [torch.randn(dims[i + 1], dims[i], device='cuda') / dims[i] ** 0.5 for i in range(L)]
+        bs = [0.3 * torch.randn(dims[i + 1], device='cuda') for i in range(L)]
+        x = torch.randn(shape[0], dims[0], *shape[1:], device='cuda')
+        gy = torch.randn(shape[0], dims[-1], *shape[1:], device='cuda')
+        ref_gx, ref_gW, ref_gb = ON.pixel_mlp_backward([w.cpu().double() for w in Ws], [b.cpu().double() for b in bs], x.cpu().double(), gy.cpu().double())
+        gx, gW, gb = ops.pixel_mlp_bwd(x, gy, Ws, bs, bf16=False)
+        assert rel_l2(gx.cpu().numpy(), ref_gx.numpy()) < 2e-5, dims
+        for l in range(L):
+            assert rel_l2(gW[l].cpu().numpy(), ref_gW[l].numpy()) < 2e-5, (dims, l)
+            assert rel_l2(gb[l].cpu().numpy(), ref_gb[l].numpy()) < 2e-5, (dims, l)
+    m = PixelMLP(4, 32).cuda()
+    x = torch.randn(2, 3, 16, 16, device='cuda', requires_grad=True)
+    y = m.train_forward(x, bf16=False)
+    y.square().sum().backward()
+    ref = ON.pixel_mlp([w.detach().cpu().double().requires_grad_(True) for w in m.weights], [b.detach().cpu().double() for b in m.biases], x.detach().cpu().double())
+    assert rel_l2(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5 and x.grad is not None and m.weights[0].grad is not None
+    wide = PixelMLP(3, 64).cuda()
     with pytest.raises(Exception):
-        ops.pixel_mlp_bwd(x, target, [w.detach() for w in m.weights], [b.detach() for b in m.biases], bf16=False)   # no float32-operand backward: loud
+        ops.pixel_mlp_bwd(x.detach(), torch.randn_like(x), [w.detach() for w in wide.weights], [b.detach() for b in wide.biases], bf16=False)   # > 32: loud

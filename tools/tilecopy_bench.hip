@@ -23,7 +23,7 @@ __device__ __forceinline__ float burn(float x, int n) {
     return x;
 }
 
-template <int C, int W, int SPREAD>
+template <int C, int W, int SPREAD, int MODE = 0>
 __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ a0, const float* __restrict__ a1, const float* __restrict__ a2,
                                                  float* __restrict__ b0, float* __restrict__ b1, float* __restrict__ b2,
                                                  int ny, int tiles_per_grid, long ntiles, int alu) {
@@ -43,13 +43,19 @@ __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ a0, c
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const size_t c = g + (size_t)(cr + RPI * i) * ny + j0 + cc;
-                r0[i] = *(const V*)(a0 + c); r1[i] = *(const V*)(a1 + c); r2[i] = *(const V*)(a2 + c);
+                if (MODE != 1) { r0[i] = *(const V*)(a0 + c); r1[i] = *(const V*)(a1 + c); r2[i] = *(const V*)(a2 + c); }
+                else { r0[i] = (V)(acc + i); r1[i] = r0[i]; r2[i] = r0[i]; }
             }
             acc = burn(acc, alu);
+            if (MODE == 2) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const size_t c = g + (size_t)(cr + RPI * i) * ny + j0 + cc;
-                *(V*)(b0 + c) = r0[i]; *(V*)(b1 + c) = r1[i]; *(V*)(b2 + c) = r2[i];
+                for (int i = 0; i < NI; ++i) acc += ((const float*)&r0[i])[0] + ((const float*)&r1[i])[0] + ((const float*)&r2[i])[0];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const size_t c = g + (size_t)(cr + RPI * i) * ny + j0 + cc;
+                    *(V*)(b0 + c) = r0[i]; *(V*)(b1 + c) = r1[i]; *(V*)(b2 + c) = r2[i];
+                }
             }
         } else {
             // same traffic, but each load group is followed by 1/NI of the ALU work and then its store group
@@ -70,11 +76,11 @@ __global__ __launch_bounds__(512) void tile_copy(const float* __restrict__ a0, c
     if (acc == 12345.678f) smem[0] = 1;
 }
 
-template <int C, int W, int SPREAD>
+template <int C, int W, int SPREAD, int MODE = 0>
 void run(const float* a, float* b, int batch, int ny, int alu, int grid) {
     const size_t fld = (size_t)batch * 1024 * ny;
     const int tpg = ny / C; const long ntiles = (long)batch * tpg;
-    auto k = tile_copy<C, W, SPREAD>;
+    auto k = tile_copy<C, W, SPREAD, MODE>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
@@ -83,7 +89,7 @@ void run(const float* a, float* b, int batch, int ny, int alu, int grid) {
             hipLaunchKernelGGL(k, dim3(grid), dim3(512), 150 * 1024, 0, a, a + fld, a + 2 * fld, b, b + fld, b + 2 * fld, ny, tpg, ntiles, alu);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
-        if (rep == 1) printf("C=%2d W=%d spread=%d alu=%5d grid=%4d : %.3f ms  %.2f TB/s\n", C, W, SPREAD, alu, grid, ms, 6.0 * fld * 4 / ms * 1e-9);
+        if (rep == 1) printf("C=%2d W=%d spread=%d mode=%d alu=%5d grid=%4d : %.3f ms  %.2f TB/s\n", C, W, SPREAD, MODE, alu, grid, ms, (MODE ? 3.0 : 6.0) * fld * 4 / ms * 1e-9);
     }
 }
 
@@ -97,6 +103,11 @@ int main() {
         run<16, 1, 0>(a, b, batch, ny, 0, grid); run<16, 4, 0>(a, b, batch, ny, 0, grid);
         run<32, 1, 0>(a, b, batch, ny, 0, grid); run<32, 4, 0>(a, b, batch, ny, 0, grid);
     }
+    // store-only and load-only bursts (mode 1 / 2): which lane width suits the 32-byte row pieces
+    run<8, 1, 0, 1>(a, b, batch, ny, 0, 2048); run<8, 2, 0, 1>(a, b, batch, ny, 0, 2048); run<8, 4, 0, 1>(a, b, batch, ny, 0, 2048);
+    run<8, 1, 0, 2>(a, b, batch, ny, 0, 2048); run<8, 2, 0, 2>(a, b, batch, ny, 0, 2048); run<8, 4, 0, 2>(a, b, batch, ny, 0, 2048);
+    run<16, 4, 0, 1>(a, b, batch, ny, 0, 2048); run<16, 4, 0, 2>(a, b, batch, ny, 0, 2048);
+    return 0;
     // with an ALU phase of about the transforms' length: burst vs spread
     for (int alu : {4000, 8000, 16000}) {
         run<8, 1, 0>(a, b, batch, ny, alu, 256); run<8, 1, 1>(a, b, batch, ny, alu, 256);
