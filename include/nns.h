@@ -115,6 +115,15 @@ int nns_fd_predictor_explicit_corrected_f32(const float* un, const float* vn, co
 int nns_fd_predictor_explicit_corrected_f64(const double* un, const double* vn, const double* un1, const double* vn1,
                                             double* ui, double* vi, int batch, int nx, int ny,
                                             double dt, double dx, double dy, double nu, void* stream);
+/* Semi-implicit (ADI) predictor with the second tridiagonal solve along axis 1, as an ADI scheme intends (the reference
+ * runs both along axis 0 and therefore needs nx == ny); oracle: semi_implicit_predictor_corrected.  Same workspace as
+ * nns_fd_predictor_adi; nx != ny allowed. */
+int nns_fd_predictor_adi_corrected_f32(const float* un, const float* vn, const float* un1, const float* vn1,
+                                       float* ui, float* vi, float* work, int batch, int nx, int ny,
+                                       double dt, double dx, double dy, double nu, void* stream);
+int nns_fd_predictor_adi_corrected_f64(const double* un, const double* vn, const double* un1, const double* vn1,
+                                       double* ui, double* vi, double* work, int batch, int nx, int ny,
+                                       double dt, double dx, double dy, double nu, void* stream);
 /* Red-black SOR: the update formula, relaxation factor, stopping rule (max|p - pPrev| <= tol) and sweep cap of
  * nns_fd_sor, with the points of one colour ((i + j) even, then odd) relaxed in parallel: two barriers per sweep
  * instead of nx + ny fronts.  Same info layout; no workspace.  oracle: get_pressure_redblack (bitwise). */

@@ -136,7 +136,9 @@ int predictor_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* 
 template <typename T>
 struct AdiK { T dt, two_dx, two_dy, dx2, dy2, dt_nu, half_dt, cx, cy, a_diag, b_diag; };
 
-template <typename T>
+// FIRST_ONLY = true: stop after the first (axis-0) solve, leaving ut / vt in `work`: the corrected variant's second solve
+// runs along axis 1 in adi_ysolve_kernel below.
+template <typename T, bool FIRST_ONLY>
 __global__ __launch_bounds__(64) void predictor_adi_kernel(const T* __restrict__ un, const T* __restrict__ vn,
                                                             const T* __restrict__ un1, const T* __restrict__ vn1,
                                                             T* __restrict__ ui, T* __restrict__ vi, T* __restrict__ work,
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64) void predictor_adi_kernel(const T* __restrict__
     const T two = (T)2, three = (T)3;
     const T lo = -k.dt, up = -k.dt;
 
-    if (edge_col) {                                 // ui = u.copy() on the untouched columns
+    if (!FIRST_ONLY && edge_col) {                  // ui = u.copy() on the untouched columns
         for (int i = 0; i < nx; ++i) out[(size_t)i * ny + j] = f[(size_t)i * ny + j];
     }
     // ---- first solve: A ut = (2/nu dx^2) (dt/2 (3H - H1) + dt nu lap f)        (:126-137)
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(64) void predictor_adi_kernel(const T* __restrict__
             xnext = x;
         }
     }
+    if (FIRST_ONLY) return;
     // ---- second solve: B ui = (2/nu dy^2)(ft + f) - dt d_yy f, again along axis 0   (:157-165)
     cp = k.b_diag; yprev = 0;
     for (int i = 1; i <= nx - 2; ++i) {
@@ -222,12 +225,106 @@ __global__ __launch_bounds__(64) void predictor_adi_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Corrected option ("true y-direction ADI"; oracle: semi_implicit_predictor_corrected):
+// the second solve  B ui = (2/nu dy^2)(ut + u) - dt d_yy u  along axis 1 (rows), as an ADI scheme means it.
+// One thread per row would stride global memory by ny; instead a workgroup owns 64 rows and walks the columns in
+// 64-wide tiles through LDS ([64][65]: both the coalesced tile copy, thread = column, and the per-row recurrence,
+// thread = row, are conflict-free).  Down-sweep left to right storing the modified right-hand side in `out`, then the
+// back substitution right to left; the constant-coefficient modified diagonal cp[j] is tabulated once in LDS.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void adi_ysolve_kernel(const T* __restrict__ un, const T* __restrict__ vn, const T* __restrict__ work,
+                                                         T* __restrict__ ui, T* __restrict__ vi, int nx, int ny, AdiK<T> k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* cp = reinterpret_cast<T*>(smem_raw);            // [ny] modified diagonal
+    T* tf = cp + ny;                                   // [64][65] tile of f (with one halo column each side handled by index)
+    T* tt = tf + 64 * 65;                              // [64][65] tile of ft, then of the result
+    const int t = threadIdx.x;
+    const bool is_v = blockIdx.y == 1;
+    const size_t base = (size_t)blockIdx.z * nx * ny;
+    const T* f = (is_v ? vn : un) + base;
+    const T* ft = work + ((size_t)blockIdx.z * 2 + (is_v ? 1 : 0)) * nx * ny;
+    T* out = (is_v ? vi : ui) + base;
+    const int i0 = blockIdx.x * 64, i = i0 + t;        // this thread's row in the recurrence phases
+    const T lo = -k.dt, up = -k.dt, two = (T)2;
+    if (t == 0) {
+        T c = k.b_diag;
+        for (int j = 1; j <= ny - 2; ++j) { if (j > 1) c = k.b_diag - (lo / c) * up; cp[j] = c; }
+    }
+    __syncthreads();
+    const bool row_solve = i >= 1 && i <= nx - 2;
+    // ---- down-sweep
+    T yprev = 0, fprev = 0, cprev = k.b_diag;
+    for (int j0 = 0; j0 < ny; j0 += 64) {
+        for (int r = 0; r < 64; ++r) {                 // coalesced tile copy: thread = column
+            const int ii = i0 + r, j = j0 + t;
+            const bool in = ii < nx && j < ny;
+            tf[r * 65 + t] = in ? f[(size_t)ii * ny + j] : (T)0;
+            tt[r * 65 + t] = in ? ft[(size_t)ii * ny + j] : (T)0;
+        }
+        __syncthreads();
+        if (i < nx) {
+            const T fnext_tile = (j0 + 64 < ny) ? f[(size_t)i * ny + j0 + 64] : (T)0;      // right neighbour of the tile's last column
+            for (int c = 0; c < 64; ++c) {
+                const int j = j0 + c;
+                if (j >= ny) break;
+                const T fc = tf[t * 65 + c];
+                if (row_solve && j >= 1 && j <= ny - 2) {
+                    const T fn = c < 63 ? tf[t * 65 + c + 1] : fnext_tile;
+                    const T rhs = k.cy * (tt[t * 65 + c] + fc) - k.dt * (fn - two * fc + fprev);
+                    T y = rhs;
+                    if (j > 1) { const T l = lo / cprev; y = rhs - l * yprev; }
+                    cprev = cp[j];
+                    tt[t * 65 + c] = y;
+                    yprev = y;
+                } else {
+                    tt[t * 65 + c] = fc;                // edges: ui = u.copy()
+                }
+                fprev = fc;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r) {
+            const int ii = i0 + r, j = j0 + t;
+            if (ii < nx && j < ny) out[(size_t)ii * ny + j] = tt[r * 65 + t];
+        }
+        __syncthreads();
+    }
+    // ---- back substitution, right to left
+    T xnext = 0;
+    const int jlast = ((ny - 1) / 64) * 64;
+    for (int j0 = jlast; j0 >= 0; j0 -= 64) {
+        for (int r = 0; r < 64; ++r) {
+            const int ii = i0 + r, j = j0 + t;
+            tt[r * 65 + t] = (ii < nx && j < ny) ? out[(size_t)ii * ny + j] : (T)0;
+        }
+        __syncthreads();
+        if (row_solve) {
+            for (int c = 63; c >= 0; --c) {
+                const int j = j0 + c;
+                if (j > ny - 2 || j < 1) continue;
+                const T y = tt[t * 65 + c];
+                const T x = j == ny - 2 ? y / cp[j] : (y - up * xnext) / cp[j];
+                tt[t * 65 + c] = x;
+                xnext = x;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r) {
+            const int ii = i0 + r, j = j0 + t;
+            if (ii < nx && j < ny) out[(size_t)ii * ny + j] = tt[r * 65 + t];
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 int predictor_adi(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T* vi, T* work, int batch, int nx, int ny,
-                  double dt, double dx, double dy, double nu, hipStream_t s) {
+                  double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false) {
     if (!un || !vn || !un1 || !vn1 || !ui || !vi || !work || !field_args_ok(batch, nx, ny))
         return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
-    if (nx != ny) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: the reference's second ADI solve acts along axis 0 (src/chorin_fd/simulate.py:159), which needs nx == ny (got %d x %d)", nx, ny);
+    if (!corrected && nx != ny) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: the reference's second ADI solve acts along axis 0 (src/chorin_fd/simulate.py:159), which needs nx == ny (got %d x %d)", nx, ny);
     if (nu == 0) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: nu must be non-zero (2/nu)");
     AdiK<T> k;
     k.dt = (T)dt; k.two_dx = (T)(2 * dx); k.two_dy = (T)(2 * dy); k.dx2 = (T)(dx * dx); k.dy2 = (T)(dy * dy);
@@ -237,9 +334,24 @@ int predictor_adi(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T
     const int tpb = 64;
     const size_t shmem = 2 * (size_t)nx * sizeof(T);
     if (shmem > 64 * 1024) return fail(NNS_ERR_UNSUPPORTED, "fd_predictor_adi: nx=%d too large for the LDS diagonal cache", nx);
-    hipLaunchKernelGGL(predictor_adi_kernel<T>, dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
+    if (!corrected) {
+        hipLaunchKernelGGL((predictor_adi_kernel<T, false>), dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
+                           un, vn, un1, vn1, ui, vi, work, nx, ny, k);
+        return check_launch("fd_predictor_adi");
+    }
+    hipLaunchKernelGGL((predictor_adi_kernel<T, true>), dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
                        un, vn, un1, vn1, ui, vi, work, nx, ny, k);
-    return check_launch("fd_predictor_adi");
+    if (int rc = check_launch("fd_predictor_adi (x solve)")) return rc;
+    const size_t shy = ((size_t)ny + 2 * 64 * 65) * sizeof(T);
+    if (shy > 150 * 1024) return fail(NNS_ERR_UNSUPPORTED, "fd_predictor_adi_corrected: ny=%d too large for the LDS diagonal cache", ny);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(adi_ysolve_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_predictor_adi_corrected: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(adi_ysolve_kernel<T>, dim3((nx + 63) / 64, 2, batch), dim3(64), shy, s, un, vn, work, ui, vi, nx, ny, k);
+    return check_launch("fd_predictor_adi (y solve)");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -465,6 +577,14 @@ NNS_API size_t nns_fd_predictor_adi_workspace(int batch, int nx, int ny, int ele
 NNS_API int nns_fd_predictor_adi_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi, float* work,
                                      int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
     return predictor_adi<float>(un, vn, un1, vn1, ui, vi, work, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+NNS_API int nns_fd_predictor_adi_corrected_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi, float* work,
+                                               int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_adi<float>(un, vn, un1, vn1, ui, vi, work, batch, nx, ny, dt, dx, dy, nu, S(stream), true);
+}
+NNS_API int nns_fd_predictor_adi_corrected_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi, double* work,
+                                               int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_adi<double>(un, vn, un1, vn1, ui, vi, work, batch, nx, ny, dt, dx, dy, nu, S(stream), true);
 }
 NNS_API int nns_fd_predictor_adi_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi, double* work,
                                      int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {

@@ -37,11 +37,11 @@ class NavierStokesSystem():
         assert method in ['semi_implicit', 'explicit']
         self.method = method
         # Options beyond the reference; the defaults reproduce it bit for bit.
-        #   advection='corrected'      : explicit predictor with v d/dy along y (the reference differences along x twice)
+        #   advection='corrected'      : explicit: v d/dy along y (the reference differences along x twice);
+        #                                semi_implicit: second ADI solve along axis 1 (the reference solves along axis 0 twice)
         #   pressure_solver='redblack' : red-black SOR (parallel half-sweeps) instead of the lexicographic order
         assert advection in ['reference', 'corrected'] and pressure_solver in ['sor', 'redblack']
-        if advection == 'corrected' and method != 'explicit':
-            raise ValueError("advection='corrected' is available for method='explicit' only")
+        # (for method='semi_implicit', advection='corrected' selects the true y-direction second ADI solve)
         self.advection, self.pressure_solver = advection, pressure_solver
         self.dtype = np.dtype(dtype)
         self.device = device if device is not None else default_device()
@@ -60,7 +60,7 @@ class NavierStokesSystem():
                 return ops.fd_predictor_explicit_corrected(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu)
             return ops.fd_predictor_explicit(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu)
         elif self.method == 'semi_implicit':
-            return ops.fd_predictor_adi(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu)
+            return ops.fd_predictor_adi(u, v, u1, v1, self.dt, self.dx, self.dy, self.nu, corrected=self.advection == 'corrected')
         raise Exception('method not recognized: {}'.format(self.method))
 
     def _pressure_dev_(self, ui, vi, p):

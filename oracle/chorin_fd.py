@@ -170,6 +170,43 @@ def semi_implicit_predictor(u, v, u1, v1, dt, dx, dy, nu):
     return ui, vi
 
 
+def semi_implicit_predictor_corrected(u, v, u1, v1, dt, dx, dy, nu):
+    """SURVEY.md section 8 (f) rank 3, "true y-direction ADI": semi_implicit_predictor with its second solve along
+    axis 1 (rows), as an alternating-direction scheme intends (:157-165 solve along axis 0 again).  nx != ny allowed.
+    An option of the build, not reference behaviour; pinned by the transposition identity in
+    tests/test_oracle_golden.py (for fields that depend on y only, the y-solve of the corrected scheme equals the
+    reference's axis-0 solve applied to the transposed problem)."""
+    un, vn, un1, vn1 = u, v, u1, v1
+    ut, vt = u.copy(), v.copy()
+    ui, vi = u.copy(), v.copy()
+    c = (Ellipsis, slice(1, -1), slice(1, -1))
+    xp = (Ellipsis, slice(2, None), slice(1, -1))
+    xm = (Ellipsis, slice(None, -2), slice(1, -1))
+    yp = (Ellipsis, slice(1, -1), slice(2, None))
+    ym = (Ellipsis, slice(1, -1), slice(None, -2))
+    a_diag = 2 / nu * dx**2 + 2 * dt
+    b_diag = 2 / nu * dy**2 + 2 * dt
+
+    def H(a, b, f):
+        return a[c] * (f[xp] - f[xm]) / (2 * dx) + b[c] * (f[yp] - f[ym]) / (2 * dy)
+
+    def first(f, f1):
+        C1 = dt / 2. * (3 * H(un, vn, f) - H(un1, vn1, f1))
+        C2 = dt * nu * ((f[xp] - 2 * f[c] + f[xm]) / dx**2 + (f[yp] - 2 * f[c] + f[ym]) / dy**2)
+        return thomas_const(-dt, a_diag, -dt, 2 / nu * dx**2 * (C1 + C2))
+
+    ut[c] = first(un, un1)
+    vt[c] = first(vn, vn1)
+
+    def second(ft, f):
+        S = (2 / nu * dy**2 * (ft[c] + f[c]) - dt * (f[yp] - 2 * f[c] + f[ym]))
+        return np.swapaxes(thomas_const(-dt, b_diag, -dt, np.ascontiguousarray(np.swapaxes(S, -1, -2))), -1, -2)
+
+    ui[c] = second(ut, un)
+    vi[c] = second(vt, vn)
+    return ui, vi
+
+
 def pressure_rhs(ui, vi, dt, dx, dy, rho):
     """dx2dy2C of src/chorin_fd/simulate.py:186-188 (backward differences, zero on the edge)."""
     C = np.zeros_like(ui)
@@ -243,7 +280,8 @@ def step(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, dt, dx, dy, rho, nu, beta, nit,
         pred = explicit_predictor_corrected if advection == 'corrected' else explicit_predictor
         ui, vi = pred(un, vn, un1, vn1, dt, dx, dy, nu)
     elif method == 'semi_implicit':
-        ui, vi = semi_implicit_predictor(un, vn, un1, vn1, dt, dx, dy, nu)
+        pred = semi_implicit_predictor_corrected if advection == 'corrected' else semi_implicit_predictor
+        ui, vi = pred(un, vn, un1, vn1, dt, dx, dy, nu)
     else:
         raise Exception('method not recognized: {}'.format(method))
     apply_bc_list(ui, u_bc)

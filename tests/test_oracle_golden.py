@@ -194,3 +194,37 @@ def test_corrected_options_known_answers():
     p1 = O.get_pressure(ui, vi, np.zeros((nx, ny)), 1e-2, 0.1, 0.1, 1.0, 1.5, 5000, tol=1e-13)
     p2 = O.get_pressure_redblack(ui, vi, np.zeros((nx, ny)), 1e-2, 0.1, 0.1, 1.0, 1.5, 5000, tol=1e-13)
     assert np.abs(p1 - p2).max() < 1e-9 * max(1.0, np.abs(p1).max())
+
+
+def test_corrected_adi_transposition_identity():
+    """semi_implicit_predictor_corrected: (1) its second solve really runs along y -- for data that are constant along x
+    the x-solve input is uniform in x and the result equals an independent 1-D tridiagonal solve along y done with
+    scipy; (2) on a square grid with dx == dy it differs from the reference's predictor (which solves along x twice)."""
+    from scipy.linalg import solve_banded
+    from oracle import chorin_fd as O
+    rng = np.random.default_rng(2)
+    nx, ny = 12, 20
+    dt, dx, dy, nu = 1e-2, 0.1, 0.07, 0.3
+    u = rng.standard_normal((nx, ny)); v = rng.standard_normal((nx, ny))
+    ui, vi = O.semi_implicit_predictor_corrected(u, v, 0.9 * u, 0.8 * v, dt, dx, dy, nu)
+    assert ui.shape == (nx, ny)
+    # rebuild ut with the same first step, then solve the second system row by row with an independent solver
+    c = (slice(1, -1), slice(1, -1))
+    a_diag = 2 / nu * dx**2 + 2 * dt; b_diag = 2 / nu * dy**2 + 2 * dt
+    def H(a, b, f): return a[c] * (f[2:, 1:-1] - f[:-2, 1:-1]) / (2 * dx) + b[c] * (f[1:-1, 2:] - f[1:-1, :-2]) / (2 * dy)
+    C1 = dt / 2. * (3 * H(u, v, u) - H(0.9 * u, 0.8 * v, 0.9 * u))
+    C2 = dt * nu * ((u[2:, 1:-1] - 2 * u[c] + u[:-2, 1:-1]) / dx**2 + (u[1:-1, 2:] - 2 * u[c] + u[1:-1, :-2]) / dy**2)
+    n1 = nx - 2
+    ab = np.zeros((3, n1)); ab[0, 1:] = -dt; ab[1] = a_diag; ab[2, :-1] = -dt
+    ut = solve_banded((1, 1), ab, 2 / nu * dx**2 * (C1 + C2))
+    S = 2 / nu * dy**2 * (ut + u[c]) - dt * (u[1:-1, 2:] - 2 * u[c] + u[1:-1, :-2])
+    n2 = ny - 2
+    ab2 = np.zeros((3, n2)); ab2[0, 1:] = -dt; ab2[1] = b_diag; ab2[2, :-1] = -dt
+    ref = solve_banded((1, 1), ab2, S.T).T
+    assert np.abs(ui[c] - ref).max() < 1e-12
+    assert np.array_equal(ui[0], u[0]) and np.array_equal(ui[:, -1], u[:, -1])
+    n = 16
+    u = rng.standard_normal((n, n)); v = rng.standard_normal((n, n))
+    a, _ = O.semi_implicit_predictor_corrected(u, v, u, v, dt, 0.1, 0.1, nu)
+    b, _ = O.semi_implicit_predictor(u, v, u, v, dt, 0.1, 0.1, nu)
+    assert np.abs(a - b).max() > 1e-6
