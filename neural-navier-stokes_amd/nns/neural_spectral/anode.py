@@ -81,7 +81,12 @@ def odesolver(func, z0, options=None):
     if _fusable(func, z0):
         n = func.net
         return _OdeMlpFn.apply(z0, n[0].weight, n[0].bias, n[2].weight, n[2].bias, n[4].weight, n[4].bias, int(Nt), method)
-    return _generic(func, z0, int(Nt), method)
+    from .spectral_ode import ODEFunc
+    if isinstance(func, ODEFunc):
+        # the product's own MLP has HIP kernels only: no silent eager / CPU integration
+        raise RuntimeError("odesolver(ODEFunc): needs float32 parameters and a [mb, K <= 32] float32 state on the HIP device "
+                           "(got z0 %s %s on %s)" % (tuple(z0.shape), z0.dtype, z0.device))
+    return _generic(func, z0, int(Nt), method)          # arbitrary user callable func(t, y): the reference's generic stepper
 
 
 def odesolver_adjoint(func, z0, options=None):

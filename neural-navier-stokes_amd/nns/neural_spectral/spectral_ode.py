@@ -68,15 +68,18 @@ class _BasisLossFn(torch.autograd.Function):
         return gc, gb, None
 
 
-def _device_path(*ts):
-    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+def _require_device(what, *ts):
+    """The expansion and its loss exist as HIP kernels only: no silent CPU / eager fallback."""
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError("%s needs float32 tensors on the HIP device (got %s on %s): the product has no CPU path"
+                               % (what, t.dtype, t.device))
 
 
 def expand(coeff, basis):
-    """coeff [T, K, C], basis [K, C, P] -> [T, C, P]; fused kernel on a HIP device, einsum elsewhere."""
-    if _device_path(coeff, basis) and coeff.shape[1] <= 32:
-        return _BasisExpandFn.apply(coeff, basis)
-    return torch.einsum('tkc,kcp->tcp', coeff, basis)
+    """coeff [T, K, C], basis [K, C, P] -> [T, C, P] by the fused HIP kernel (K <= 32; larger K fails in the C ABI)."""
+    _require_device('basis expansion', coeff, basis)
+    return _BasisExpandFn.apply(coeff, basis)
 
 
 class PDEFunc(nn.Module):
@@ -111,9 +114,8 @@ class PDEFunc(nn.Module):
         mb, nt = grid0.size(0), t.size(0)
         coeff, basis = self._coeff(mb, nt), self._basis()
         o = obs.reshape(nt * mb, 3, self.nx * self.ny)
-        if _device_path(coeff, basis, o) and self.K <= 32:
-            return _BasisLossFn.apply(coeff, basis, o)
-        return torch.norm(torch.einsum('tkc,kcp->tcp', coeff, basis) - o, p=2)
+        _require_device('basis loss', coeff, basis, o)
+        return _BasisLossFn.apply(coeff, basis, o)
 
     def basis_weight_mat(self):
         W = []

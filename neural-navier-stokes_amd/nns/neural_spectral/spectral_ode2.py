@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .anode import odesolver_adjoint as odesolver
-from .spectral_ode import ODEFunc, AverageMeter, expand, _BasisLossFn, _device_path  # noqa: F401
+from .spectral_ode import ODEFunc, AverageMeter, expand, _BasisLossFn, _require_device  # noqa: F401
 
 
 class PDEFunc(nn.Module):
@@ -45,6 +45,5 @@ class PDEFunc(nn.Module):
         mb, nt = grid0.size(0), t.size(0)
         coeff, basis = self._coeff(mb, nt), self._basis()
         o = obs.reshape(nt * mb, 3, self.nx * self.ny)
-        if _device_path(coeff, basis, o) and self.K <= 32:
-            return _BasisLossFn.apply(coeff, basis, o)
-        return torch.norm(torch.einsum('tkc,kcp->tcp', coeff, basis) - o, p=2)
+        _require_device('basis loss', coeff, basis, o)
+        return _BasisLossFn.apply(coeff, basis, o)

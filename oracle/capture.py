@@ -325,7 +325,51 @@ def worker_neural():
     np.savez_compressed(os.path.join(GOLD, 'neural_spectral.npz'), **out)
 
 
-WORKERS = dict(boundary=worker_boundary, chorin_fd=worker_chorin_fd, direct_fd=worker_direct_fd,
+def worker_rnn():
+    """GRU baselines: src/neural_spectral/spectral_rnn.py PDEFunc (GRU coefficient
+    dynamics + basis expansion) and src/neural_spectral/rnn.py RNN (black-box next-frame GRU + MLP)."""
+    import types
+    stub = types.ModuleType('torchdiffeq')           # accommodation 1 (imported, unused: spectral_rnn.py:10)
+    stub.odeint_adjoint = None
+    sys.modules['torchdiffeq'] = stub
+    import torch
+    torch.manual_seed(1)
+    import src.neural_spectral.spectral_rnn as SR
+    import src.neural_spectral.rnn as R
+
+    def dump(model):
+        return {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+    out = {}
+    K, nx, ny, nt = 4, 8, 8, 6
+    model = SR.PDEFunc(K, nx, ny)
+    for k, v in dump(model).items():
+        out['sr_param_' + k] = v
+    for mb in (1, 2):
+        obs = torch.randn(nt, mb, 3, nx, ny)
+        t = torch.arange(nt) + 1
+        model.zero_grad()
+        pred = model(obs[0], t)
+        loss = torch.norm(pred - obs, p=2)
+        loss.backward()
+        pre = 'sr_mb%d_' % mb
+        out[pre + 'obs'] = obs.numpy().copy()
+        out[pre + 'pred'] = pred.detach().numpy().copy()
+        out[pre + 'loss'] = np.float64(loss.item())
+        for n_, p_ in model.named_parameters():
+            out[pre + 'grad_' + n_] = p_.grad.detach().numpy().copy()
+    out['sr_diversity_penalty'] = np.float64(model.diversity_penalty().item())
+    rnn = R.RNN(3 * nx * ny, hidden_dim=32)
+    for k, v in dump(rnn).items():
+        out['rnn_param_' + k] = v
+    seq = torch.randn(1, nt, 3 * nx * ny)           # batch 1, as the reference driver (its .view fails on larger batches)
+    o, hdn = rnn(seq)
+    out['rnn_in'], out['rnn_out'], out['rnn_hid'] = seq.numpy().copy(), o.detach().numpy().copy(), hdn.detach().numpy().copy()
+    out['rnn_extrapolate'] = rnn.extrapolate(seq[:1, :1], 4).numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, 'neural_rnn.npz'), **out)
+
+
+WORKERS = dict(rnn=worker_rnn, boundary=worker_boundary, chorin_fd=worker_chorin_fd, direct_fd=worker_direct_fd,
                chorin_spectral=worker_chorin_spectral, neural=worker_neural)
 
 
@@ -337,7 +381,8 @@ def main():
         raise SystemExit("reference not present at %s: capture only runs in the build container" % REF)
     os.makedirs(GOLD, exist_ok=True)
     env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE='1')
-    for name in WORKERS:
+    only = [a for a in sys.argv[1:] if a in WORKERS]            # e.g. `python oracle/capture.py rnn` regenerates one fixture
+    for name in (only or WORKERS):
         print('capturing', name, flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', name], check=True, env=env,
                        cwd='/tmp')

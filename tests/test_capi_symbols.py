@@ -61,3 +61,24 @@ def test_reference_import_paths_resolve_to_nns():
         B.DirichletBoundaryCondition(0, 'left', 1, 0.2)          # dx must be float (src/boundary.py:17)
     with pytest.raises(AssertionError):
         B.DirichletBoundaryCondition(0, 'front', 0.1, 0.2)
+
+
+def test_mirrors_have_no_cpu_fallback():
+    """The neural mirrors' compute exists as HIP kernels only: CPU tensors must raise, not run an eager stand-in."""
+    import pytest
+    import torch
+    from nns.neural_spectral import spectral_ode, spectral_rnn
+    from nns.neural_spectral.anode import odesolver
+    m = spectral_ode.PDEFunc(2, 4, 4)
+    t = torch.arange(3) + 1
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 4, 4), t)                       # ODEFunc integration off-device
+    with pytest.raises(RuntimeError):
+        spectral_ode.expand(torch.zeros(3, 2, 3), torch.zeros(2, 3, 16))
+    with pytest.raises(RuntimeError):
+        spectral_rnn.PDEFunc(2, 4, 4)(torch.zeros(1, 3, 4, 4), t)
+    with pytest.raises(RuntimeError):
+        odesolver(spectral_ode.ODEFunc(6), torch.zeros(1, 6), {'Nt': 2, 'method': 'RK4'})
+    # an arbitrary user callable still goes through the reference's generic stepper (API parity, not a kernel fallback)
+    out = odesolver(lambda t_, y: -y, torch.ones(1, 2), {'Nt': 4, 'method': 'RK4'})
+    assert out.shape == (4, 1, 2) and abs(out[-1, 0, 0].item() - 0.3679) < 1e-3

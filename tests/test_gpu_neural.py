@@ -273,3 +273,39 @@ def test_pixel_mlp_backward_float32(gpu_device):
     wide = PixelMLP(3, 64).cuda()
     with pytest.raises(Exception):
         ops.pixel_mlp_bwd(x.detach(), torch.randn_like(x), [w.detach() for w in wide.weights], [b.detach() for b in wide.biases], bf16=False)   # > 32: loud
+
+
+def test_gru_baselines_vs_golden(gpu_device):
+    """the GRU variants against outputs captured from the reference
+    (tests/golden/neural_rnn.npz).  spectral_rnn.PDEFunc: GRU recurrence on MIOpen, expansion / loss / gradients on the
+    fused HIP kernels; rnn.RNN: forward, hidden state and the autoregressive extrapolation."""
+    from src.neural_spectral.spectral_rnn import PDEFunc
+    from src.neural_spectral.rnn import RNN
+    GR = load_golden('neural_rnn.npz')
+    K, nx, ny, nt = 4, 8, 8, 6
+    m = PDEFunc(K, nx, ny)
+    m.load_state_dict({k[len('sr_param_'):]: T(GR[k], device='cpu') for k in GR.files if k.startswith('sr_param_')}, strict=True)
+    m = m.cuda()
+    for mb in (1, 2):
+        pre = 'sr_mb%d_' % mb
+        obs = T(GR[pre + 'obs'])
+        t = torch.arange(nt, device='cuda') + 1
+        pred = m(obs[0], t)
+        assert pred.shape == (nt, mb, 3, nx, ny)
+        assert rel_l2(pred.detach().cpu().numpy(), GR[pre + 'pred']) < 1e-5
+        m.zero_grad()
+        loss = m.loss(obs[0], t, obs)                                  # fused loss kernel
+        assert abs(loss.item() - float(GR[pre + 'loss'])) < 1e-5 * float(GR[pre + 'loss'])
+        loss.backward()
+        for n_, p_ in m.named_parameters():
+            assert rel_l2(p_.grad.cpu().numpy(), GR[pre + 'grad_' + n_]) < 2e-4, n_
+    assert abs(m.diversity_penalty().item() - float(GR['sr_diversity_penalty'])) < 1e-6
+    r = RNN(3 * nx * ny, hidden_dim=32)
+    r.load_state_dict({k[len('rnn_param_'):]: T(GR[k], device='cpu') for k in GR.files if k.startswith('rnn_param_')}, strict=True)
+    r = r.cuda()
+    o, hdn = r(T(GR['rnn_in']))
+    assert rel_l2(o.detach().cpu().numpy(), GR['rnn_out']) < 1e-5 and rel_l2(hdn.detach().cpu().numpy(), GR['rnn_hid']) < 1e-5
+    ex = r.extrapolate(T(GR['rnn_in'])[:1, :1], 4)
+    assert ex.shape == (1, 4, 3 * nx * ny) and rel_l2(ex.numpy(), GR['rnn_extrapolate']) < 1e-5
+    o2, _ = r(torch.randn(3, nt, 3 * nx * ny, device='cuda'))          # batches > 1 work here (the reference's .view does not)
+    assert o2.shape == (3, nt, 3 * nx * ny)
