@@ -353,6 +353,19 @@ __global__ __launch_bounds__(256) void basis_expand_kernel(const float* __restri
     }
 }
 
+// one step of the transposing butterfly (see basis_loss_kernel): values [0, 2M) -> [0, M)
+constexpr int kPart = 32;            // values per butterfly: TT time rows x KMAX coefficients, reduced within each 32-lane half
+template <int M>
+__device__ __forceinline__ void halve(float (&part)[kPart], int lane) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int e = 0; e < M; ++e) {
+        const float send = up ? part[e] : part[e + M];
+        const float keep = up ? part[e + M] : part[e];
+        part[e] = keep + __shfl_xor(send, M);
+    }
+}
+
 // Fused loss / gradient pass.  A workgroup owns (channel c, a tile of 256*PPT pixels) and walks all T time
 // rows: the K basis values of its pixels stay in registers, obs is streamed ONCE (4 B per element -- the
 // compulsory traffic), pred is never written.  MODE 0: sumsq += (pred-obs)^2.  MODE 2: g is READ from `obs`
@@ -365,7 +378,10 @@ __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict
                                                          float* __restrict__ gcoeff, float* __restrict__ gbasis, float scale,
                                                          int T, int K, int C, int P, int TC, int rows_per_split, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* cw = reinterpret_cast<float*>(smem_raw);                  // [TC][K] coefficients of this channel, one chunk of time rows
+    // [TC][KMAX] coefficients of this channel for one chunk of time rows, ZERO-PADDED from K to KMAX: the hot loop runs
+    // over all KMAX coefficients with no `k < K` guard (guards inside unrolled loops become a branch forest with
+    // conservative waits: 125 scalar instructions and 65 % s_waitcnt per row in the first version)
+    float* cw = reinterpret_cast<float*>(smem_raw);
     const int c = blockIdx.y, tid = threadIdx.x, lane = tid % kWave;
     const int pbase = blockIdx.x * 256 * PPT + tid;
     // the time axis is split over blockIdx.z so that a launch has >= ~2048 workgroups even when P*C is small
@@ -373,48 +389,84 @@ __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict
     const int t_lo = blockIdx.z * rows_per_split, t_hi = min(T, t_lo + rows_per_split);
     float fk[PPT][KMAX], gb[PPT][KMAX];
     bool ok[PPT];
+    int pix[PPT];                                                     // clamped pixel index: loads never need a mask
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         ok[i] = pbase + 256 * i < P;
+        pix[i] = ok[i] ? pbase + 256 * i : P - 1;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) { fk[i][k] = (ok[i] && k < K) ? basis[((size_t)k * C + c) * P + pbase + 256 * i] : 0.f; gb[i][k] = 0.f; }
+        for (int k = 0; k < KMAX; ++k) { fk[i][k] = (ok[i] && k < K) ? basis[((size_t)k * C + c) * P + pix[i]] : 0.f; gb[i][k] = 0.f; }
     }
     double local = 0.0;
+    // gcoeff[t][k][c] = sum over pixels: per-lane partial sums of TT time rows x KMAX coefficients (32 values) are
+    // combined by ONE transposing butterfly within each 32-lane half (lane l ends up with its half's total of value
+    // l mod 32) and leave in ONE atomic wave-instruction -- not K reductions and K single-lane atomics per time row
+    // (63 M atomic instructions at the ensemble shape of BASELINE config 5).
+    constexpr int TT = kPart / KMAX;
+    float part[kPart];
+#pragma unroll
+    for (int e = 0; e < kPart; ++e) part[e] = 0.f;
+    auto flush_part = [&](int t_first) {
+        // recursive halving: at distance m a lane keeps the half of its values whose index bit matches its lane bit
+        halve<16>(part, lane); halve<8>(part, lane); halve<4>(part, lane); halve<2>(part, lane); halve<1>(part, lane);
+        const int v = lane & (kPart - 1), tt = v / KMAX, k = v % KMAX;
+        if (k < K && t_first + tt < t_hi) atomicAdd(&gcoeff[((size_t)(t_first + tt) * K + k) * C + c], part[0]);
+#pragma unroll
+        for (int e = 0; e < kPart; ++e) part[e] = 0.f;
+    };
     for (int t0 = t_lo; t0 < t_hi; t0 += TC) {
         const int tn = min(TC, t_hi - t0);
+        const int tnp = (tn + TT - 1) / TT * TT;                     // padded to whole groups: the padding rows have zero coefficients
         __syncthreads();
-        for (int e = tid; e < tn * K; e += 256) cw[e] = coeff[((size_t)t0 * K + e) * C + c];
+        for (int e = tid; e < tnp * KMAX; e += 256) {
+            const int tt = e / KMAX, k = e % KMAX;
+            cw[e] = (tt < tn && k < K) ? coeff[((size_t)(t0 + tt) * K + k) * C + c] : 0.f;
+        }
         __syncthreads();
-        for (int tt = 0; tt < tn; ++tt) {
-            const int t = t0 + tt;
-            float ob[PPT];
+        // observations are requested one row ahead (clamped row index: the extra load of the last row is harmless)
+        float obn[PPT];
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) ob[i] = ok[i] ? obs[((size_t)t * C + c) * P + pbase + 256 * i] : 0.f;     // PPT independent loads in flight
-            float g[PPT];
+        for (int i = 0; i < PPT; ++i) obn[i] = obs[((size_t)t0 * C + c) * P + pix[i]];
+        for (int tt0 = 0; tt0 < tnp; tt0 += TT) {
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                float pred = 0.f;
-                if (MODE != 2) {
+            for (int tq = 0; tq < TT; ++tq) {
+                const int tt = tt0 + tq;
+                const bool row_ok = tt < tn;                                           // uniform
+                float ob[PPT];
 #pragma unroll
-                    for (int k = 0; k < KMAX; ++k) if (k < K) pred = fmaf(cw[tt * K + k], fk[i][k], pred);
+                for (int i = 0; i < PPT; ++i) ob[i] = obn[i];
+                const int tnext = tt + 1 < tn ? tt + 1 : tn - 1;
+#pragma unroll
+                for (int i = 0; i < PPT; ++i) obn[i] = obs[((size_t)(t0 + tnext) * C + c) * P + pix[i]];
+                float w[KMAX];                                                        // this row's coefficients, read once
+#pragma unroll
+                for (int k4 = 0; k4 < KMAX; k4 += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(cw + tt * KMAX + k4);
+                    w[k4] = q.x; w[k4 + 1] = q.y; w[k4 + 2] = q.z; w[k4 + 3] = q.w;
                 }
-                const float r = MODE == 2 ? ob[i] : (ok[i] ? pred - ob[i] : 0.f);
-                if (MODE == 0) local += (double)r * (double)r;
-                g[i] = MODE == 2 ? r : scale * r;
-            }
-            if (MODE != 0) {
+                float g[PPT];
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    if (k < K) {
-                        const float w = cw[tt * K + k];
+                for (int i = 0; i < PPT; ++i) {
+                    float pred = 0.f;
+                    if (MODE != 2) {
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k) pred = fmaf(w[k], fk[i][k], pred);
+                    }
+                    const float r = (ok[i] && row_ok) ? (MODE == 2 ? ob[i] : pred - ob[i]) : 0.f;
+                    if (MODE == 0) local += (double)r * (double)r;
+                    g[i] = MODE == 2 ? r : scale * r;
+                }
+                if (MODE != 0) {
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
                         float sred = 0.f;
 #pragma unroll
-                        for (int i = 0; i < PPT; ++i) { gb[i][k] = fmaf(w, g[i], gb[i][k]); sred = fmaf(fk[i][k], g[i], sred); }
-                        for (int o = kWave / 2; o > 0; o >>= 1) sred += __shfl_down(sred, o);
-                        if (lane == 0) atomicAdd(&gcoeff[((size_t)t * K + k) * C + c], sred);
+                        for (int i = 0; i < PPT; ++i) { gb[i][k] = fmaf(w[k], g[i], gb[i][k]); sred = fmaf(fk[i][k], g[i], sred); }
+                        part[tq * KMAX + k] = sred;
                     }
                 }
             }
+            if (MODE != 0) flush_part(t0 + tt0);
         }
     }
     if (MODE == 0) {
@@ -449,10 +501,13 @@ inline LossGeom loss_geom(int T, int K, int C, int P) {
     if (ns > 65535) ns = 65535;
     g.rows_per_split = (T + ns - 1) / ns;
     g.nsplit = (T + g.rows_per_split - 1) / g.rows_per_split;
-    const int cap = 8192 / K;                                              // <= 32 KB of coefficients per chunk
+    const int kmax = g.ppt == 4 ? 16 : kMaxK;                              // the kernel pads the coefficients to KMAX
+    const int tt = 32 / kmax;
+    int cap = 8192 / kmax;                                                 // <= 32 KB of coefficients per chunk
     g.TC = g.rows_per_split < cap ? g.rows_per_split : cap;
+    g.TC = (g.TC + tt - 1) / tt * tt;                                      // whole groups of TT rows
     g.grid = dim3(bx, C, g.nsplit);
-    g.lds = (size_t)g.TC * K * sizeof(float);
+    g.lds = (size_t)g.TC * kmax * sizeof(float);
     return g;
 }
 
