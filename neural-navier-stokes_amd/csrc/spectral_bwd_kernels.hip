@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_bwd_xpass_kernel(const floa
         const int line = wave * L::FPW + sub;
         unsigned char* xb = lines + (size_t)line * L::LINE_BYTES;
         float* my_stage = reinterpret_cast<float*>(xb) + (line % L::SKEW_MOD) * L::SKEW_DW;
-        const long lt = xcd_remap((unsigned)t, (unsigned)ntiles);
+        const long lt = ntiles - 1 - (long)xcd_remap((unsigned)t, (unsigned)ntiles);      // last grid first: see spectral_kernels.hip launch_xpass
         const int j0 = (int)(lt % tiles_per_grid) * CW;
         const size_t g = (size_t)(lt / tiles_per_grid) * N * ny;
         const int cc = tx % CW, cr = tx / CW;
