@@ -292,3 +292,38 @@ def test_spectral_residual_backward_vs_oracle(gpu_device, shape):
     ref = OP.spectral_residual_vjp(f[0].astype(np.float64), f[1].astype(np.float64), 2 * r[0] / N, 2 * r[1] / N, 2 * r[2] / N, dt, Lx, Ly, rho, nu)
     for tt, rr in zip(t, ref):
         assert rel_l2(tt.grad.cpu().numpy(), rr) < 2e-5
+
+
+@pytest.mark.parametrize("backend", ["fd5", "fd9", "spectral"])
+def test_backward_adjoint_identity_full_size(gpu_device, backend):
+    """Size-independent property at BASELINE's grid size (1024^2): <J d, g> = <d, J^T g> with both sides from the HIP
+    kernels.  The residual is quadratic in (u, v) and linear in the rest, so J d = (r(w + d) - r(w - d)) / 2 exactly up
+    to float32 rounding; sums are accumulated in float64."""
+    from nns.periodic import ResidualEngine
+    from nns.synthetic import residual_inputs
+    n, B = 1024, 2
+    eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
+    w = [torch.as_tensor(a, device='cuda') for a in residual_inputs(B, n)]
+    g = torch.Generator(device='cuda').manual_seed(3)
+    def smooth():
+        f = torch.randn(B, n, n, device='cuda', generator=g)
+        F = torch.fft.rfft2(f)
+        kx = torch.fft.fftfreq(n, 1.0 / n, device='cuda').abs()[:, None]; ky = torch.fft.rfftfreq(n, 1.0 / n, device='cuda')[None, :]
+        s = torch.fft.irfft2(F * torch.exp(-(kx**2 + ky**2) / 200.0), s=(n, n))
+        return (s / s.abs().max()).contiguous()
+    d = [0.05 * smooth() for _ in range(5)]
+    gr = [smooth() for _ in range(3)]
+    rp = eng(*[a + b for a, b in zip(w, d)])
+    rp = [t.clone() for t in rp]
+    rm = eng(*[a - b for a, b in zip(w, d)])
+    Jd = [(a.double() - b.double()) / 2 for a, b in zip(rp, rm)]
+    lhs = sum((a * b.double()).sum().item() for a, b in zip(Jd, gr))
+    if backend == 'spectral':
+        from nns import ops
+        grads = ops.spec_residual_bwd(w[0], w[1], *gr, eng.dt, eng.Lx, eng.Ly, eng.rho, eng.nu)
+    else:
+        from nns import ops
+        grads = ops.fd_residual_bwd(w[0], w[1], *gr, eng.dt, eng.dx, eng.dy, eng.rho, eng.nu, 5 if backend == 'fd5' else 9)
+    rhs = sum((a.double() * b.double()).sum().item() for a, b in zip(grads, d))
+    scale = sum((a.abs() * b.double().abs()).sum().item() for a, b in zip(Jd, gr))
+    assert abs(lhs - rhs) < 2e-4 * scale, (lhs, rhs, scale)
