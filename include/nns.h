@@ -132,6 +132,15 @@ int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, int batch, in
 int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, int batch, int nx, int ny,
                             double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
 
+/* One red-black HALF-sweep on a row slab p[nxl][ny] whose rows 0 and nxl-1 are halo / boundary rows (not written);
+ * local row i is global row gi0 + i (that fixes the colours).  Multi-workgroup.  *err_bits (4 bytes for f32, 8 for f64,
+ * zeroed by the caller) receives max|p_new - p_old| as an IEEE bit pattern via an unsigned atomic max.  Building block
+ * of the sharded pressure solve (nns/slab.py: SlabPressure) and of red-black SOR on grids too large for LDS. */
+int nns_fd_sor_redblack_halfsweep_f32(float* p, const float* C, void* err_bits, int nxl, int ny, int gi0, int colour,
+                                      double dx, double dy, double beta, void* stream);
+int nns_fd_sor_redblack_halfsweep_f64(double* p, const double* C, void* err_bits, int nxl, int ny, int gi0, int colour,
+                                      double dx, double dy, double beta, void* stream);
+
 /* _correction_step (:204-210): u = u* - dt/(2dx) d0x p, v = v* - dt/(2dy) d0y p; edges from u*. */
 int nns_fd_correction_f32(const float* ui, const float* vi, const float* p, float* u, float* v,
                           int batch, int nx, int ny, double dt, double dx, double dy, void* stream);

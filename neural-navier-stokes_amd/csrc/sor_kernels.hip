@@ -217,6 +217,62 @@ int sor_redblack(T* p, const T* C, T* info, int batch, int nx, int ny, double dx
     return check_launch("fd_sor_redblack");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// One red-black HALF-sweep on a row slab (the opt-in sharded pressure solve).  p is
+// [nxl][ny] with rows 0 and nxl-1 acting as halo / physical-boundary rows (never written); row i of the slab is global
+// row gi0 + i, which fixes the colour of its points.  Multi-workgroup (one thread per colour point), so it also serves
+// single-GPU grids too large for the LDS-resident kernel.  max|p_new - p_old| is folded into *err_bits with an
+// unsigned atomic max on the IEEE bit pattern (order-preserving for non-negative values; the caller zeroes it).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T> struct BitsOf;
+template <> struct BitsOf<float> { using U = unsigned int; };
+template <> struct BitsOf<double> { using U = unsigned long long; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void sor_rb_halfsweep_kernel(T* __restrict__ p, const T* __restrict__ C, typename BitsOf<T>::U* __restrict__ err_bits,
+                                                                int nxl, int ny, int gi0, int colour, SorK<T> k) {
+    using U = typename BitsOf<T>::U;
+    __shared__ T wave_e[256 / kWave];
+    const int hw = (ny - 2 + 1) / 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    T e = (T)0;
+    if (q < hw) {
+        for (int i = blockIdx.y + 1; i <= nxl - 2; i += gridDim.y) {   // interior rows 1 .. nxl-2, a strided share per block
+            const int j = 1 + 2 * q + ((gi0 + i + 1 + colour) & 1);     // (global row + j) % 2 == colour
+            if (j <= ny - 2) {
+                const size_t c = (size_t)i * ny + j;
+                const T old = p[c];
+                const T nw = k.beta * (k.dy2 * p[c + ny] + k.dy2 * p[c - ny] + k.dx2 * p[c + 1] + k.dx2 * p[c - 1] - C[c]) / k.den + k.omb * old;
+                p[c] = nw;
+                e = nanmax<T>(e, fabs(nw - old));
+            }
+        }
+    }
+    // one atomic per block at most, and none when the running maximum already covers this block's value: same-address
+    // atomics serialise in L2 (~11 ns each), which at one per wave cost 30x the sweep's memory time
+    for (int off = kWave / 2; off > 0; off >>= 1) e = nanmax<T>(e, __shfl_xor(e, off));
+    if ((threadIdx.x & (kWave - 1)) == 0) wave_e[threadIdx.x / kWave] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; ++w) e = nanmax<T>(e, wave_e[w]);
+        const U bits = __builtin_bit_cast(U, e);
+        if (bits > __hip_atomic_load(err_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(err_bits, bits);
+    }
+}
+
+template <typename T>
+int sor_rb_halfsweep(T* p, const T* C, void* err_bits, int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, hipStream_t s) {
+    if (!p || !C || !err_bits || nxl < 3 || ny < 3 || (colour != 0 && colour != 1) || gi0 < 0)
+        return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack_halfsweep: bad args (nxl=%d ny=%d gi0=%d colour=%d)", nxl, ny, gi0, colour);
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)0};
+    const int hw = (ny - 2 + 1) / 2;
+    const int gx = (hw + 255) / 256, gy = std::min(nxl - 2, std::max(1, 2048 / gx));
+    hipLaunchKernelGGL(sor_rb_halfsweep_kernel<T>, dim3(gx, gy), dim3(256), 0, s, p, C,
+                       static_cast<typename BitsOf<T>::U*>(err_bits), nxl, ny, gi0, colour, k);
+    return check_launch("fd_sor_redblack_halfsweep");
+}
+
 }  // namespace
 
 NNS_API size_t nns_fd_sor_workspace(int batch, int nx, int ny, int elem_size) {
@@ -239,4 +295,13 @@ NNS_API int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, int b
 NNS_API int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, int batch, int nx, int ny, double dx, double dy,
                                     double beta, double tol, int max_sweeps, void* stream) {
     return sor_redblack<double>(p, C, info, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+
+NNS_API int nns_fd_sor_redblack_halfsweep_f32(float* p, const float* C, void* err_bits, int nxl, int ny, int gi0, int colour,
+                                              double dx, double dy, double beta, void* stream) {
+    return sor_rb_halfsweep<float>(p, C, err_bits, nxl, ny, gi0, colour, dx, dy, beta, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_redblack_halfsweep_f64(double* p, const double* C, void* err_bits, int nxl, int ny, int gi0, int colour,
+                                              double dx, double dy, double beta, void* stream) {
+    return sor_rb_halfsweep<double>(p, C, err_bits, nxl, ny, gi0, colour, dx, dy, beta, reinterpret_cast<hipStream_t>(stream));
 }

@@ -38,6 +38,7 @@ _DUAL = {
     'nns_fd_pressure_rhs': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_sor': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_sor_redblack': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_fd_sor_redblack_halfsweep': [_P] * 3 + [_I] * 4 + [_D] * 3 + [_P],
     'nns_fd_correction': [_P] * 5 + [_I] * 3 + [_D] * 3 + [_P],
     'nns_fd_build_b': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_jacobi': [_P] * 3 + [_I] * 3 + [_D] * 2 + [_I, _BCP, _P],

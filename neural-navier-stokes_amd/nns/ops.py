@@ -135,6 +135,16 @@ def fd_sor_redblack_(p, C, dx, dy, beta, tol, max_sweeps):
     return info
 
 
+def fd_sor_redblack_halfsweep_(p, C, err, gi0, colour, dx, dy, beta):
+    """One red-black half-sweep in place on a row slab p [nxl, ny] (rows 0 and nxl-1 = halo / boundary rows).
+    err: a zeroed one-element tensor of p's dtype; afterwards err.max-accumulates max|p_new - p_old| (bit pattern)."""
+    if p.dim() != 2 or p.shape != C.shape or not p.is_cuda or not p.is_contiguous() or not C.is_contiguous():
+        raise ValueError("fd_sor_redblack_halfsweep_: p, C must be contiguous 2-D device tensors of one shape")
+    suf = '_f32' if p.dtype == torch.float32 else '_f64'
+    _call('nns_fd_sor_redblack_halfsweep', suf, _p(p), _p(C), _p(err), p.shape[0], p.shape[1], int(gi0), int(colour), dx, dy, beta, _stream())
+    return err
+
+
 def fd_correction(ui, vi, p, dt, dx, dy):
     suf, (B, nx, ny) = _chk(ui, vi, p)
     u, v = torch.empty_like(ui), torch.empty_like(vi)

@@ -11,7 +11,8 @@ GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
     transposes u, v, p (packed) to column slabs [B, nx, ny/P], the x-pass kernel runs there, and ONE
     all-to-all brings the three partial fields back -- 2 collectives per evaluation instead of 10 for a
     library-style 2-D FFT per derivative.  An all-to-all uses all 7 xGMI links of a GPU concurrently.
-  * SOR does not shard (sequential fronts): replicas only.
+  * SOR in the reference's lexicographic order does not shard (sequential fronts): replicas only.  The opt-in
+    RED-BLACK order does (SlabPressure below): one halo exchange per half-sweep and one all-reduce(max) per sweep.
 
 The compute callables default to the HIP ops; the CPU tests inject oracle-based ones to check the
 decomposition logic (index ranges, packing, wrap-around) against the single-process result.
@@ -117,3 +118,86 @@ class SlabResidual(object):
 
     def both(self, u, v, p, u_prev, v_prev, stencil=5):
         return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev)
+
+
+class HipSorCompute(object):
+    """Half-sweep back-end of SlabPressure: the HIP kernel nns_fd_sor_redblack_halfsweep_*."""
+
+    def halfsweep(self, p, C, err, gi0, colour, dx, dy, beta):
+        from . import ops
+        return ops.fd_sor_redblack_halfsweep_(p, C, err, gi0, colour, dx, dy, beta)
+
+    def err_value(self, err):
+        return err          # the kernel max-accumulates the IEEE bit pattern of a non-negative value: it reads back as that value
+
+
+class SlabPressure(object):
+    """Red-black SOR for the pressure Poisson problem of chorin_fd on a NON-periodic [nx, ny] grid, rows sharded over
+    ranks ("opt-in red-black shards like Jacobi; global err needs all-reduce(max)").
+
+    Rank r owns interior-or-boundary rows [lo, hi) of the global grid; its working slab is those rows plus one halo row
+    on each side that has a neighbour (the physical boundary rows 0 and nx-1 belong to the first / last rank and are
+    never updated, exactly as in the single-process solver).  Per half-sweep: refresh the halo rows from the ring
+    neighbours (no wrap: the domain is not periodic), relax one colour; per sweep: all-reduce(max) of the local
+    max|p - pPrev|.  Same formula, relaxation factor, stopping rule and sweep cap as nns_fd_sor_redblack; the result is
+    bitwise the single-process red-black solve (a half-sweep only reads the other colour)."""
+
+    def __init__(self, nx, ny, dx, dy, beta, tol=5e-6, group=None, compute=None):
+        self.group = group
+        self.P = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if nx < 3 * self.P:
+            raise ValueError("need at least 3 rows per rank (nx=%d over %d ranks)" % (nx, self.P))
+        base, rem = divmod(nx, self.P)
+        counts = [base + (1 if r < rem else 0) for r in range(self.P)]
+        self.lo = sum(counts[:self.rank]); self.hi = self.lo + counts[self.rank]
+        self.nx, self.ny, self.dx, self.dy, self.beta, self.tol = nx, ny, dx, dy, beta, tol
+        self.has_up, self.has_down = self.rank > 0, self.rank < self.P - 1
+        self.compute = compute if compute is not None else HipSorCompute()
+
+    def local_rows(self, full):
+        """This rank's rows of a global [nx, ny] array."""
+        return full[self.lo:self.hi]
+
+    def _exchange(self, slab):
+        """slab: [nloc + has_up + has_down, ny]; refresh its halo rows from the neighbours' edge rows."""
+        reqs = []
+        first = slab[1 if self.has_up else 0].contiguous()
+        last = slab[-2 if self.has_down else -1].contiguous()
+        top = torch.empty_like(first) if self.has_up else None
+        bot = torch.empty_like(last) if self.has_down else None
+        if self.has_up:
+            reqs += [dist.isend(first, self.rank - 1, group=self.group), dist.irecv(top, self.rank - 1, group=self.group)]
+        if self.has_down:
+            reqs += [dist.isend(last, self.rank + 1, group=self.group), dist.irecv(bot, self.rank + 1, group=self.group)]
+        for q in reqs:
+            q.wait()
+        if self.has_up:
+            slab[0].copy_(top)
+        if self.has_down:
+            slab[-1].copy_(bot)
+
+    def solve_(self, p_loc, C_loc, max_sweeps):
+        """p_loc, C_loc: this rank's rows [hi - lo, ny] (p is updated in place).  Returns (sweeps done, last err)."""
+        up, down = int(self.has_up), int(self.has_down)
+        nloc = self.hi - self.lo
+        slab = torch.zeros(nloc + up + down, self.ny, dtype=p_loc.dtype, device=p_loc.device)
+        cs = torch.zeros_like(slab)
+        slab[up:up + nloc].copy_(p_loc)
+        cs[up:up + nloc].copy_(C_loc)
+        gi0 = self.lo - up                                   # global row of slab row 0
+        err_buf = torch.zeros(1, dtype=p_loc.dtype, device=p_loc.device)
+        err, done = 1.0, 0
+        while done < max_sweeps and err > self.tol:
+            err_buf.zero_()
+            for colour in (0, 1):
+                if self.P > 1:
+                    self._exchange(slab)
+                self.compute.halfsweep(slab, cs, err_buf, gi0, colour, self.dx, self.dy, self.beta)
+            e = self.compute.err_value(err_buf).clone()
+            if self.P > 1:
+                dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)
+            err = float(e.item())
+            done += 1
+        p_loc.copy_(slab[up:up + nloc])
+        return done, err

@@ -364,6 +364,65 @@ def test_corrected_options_vs_oracle(gpu_device, dtype):
 
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_sharded_redblack_halfsweep(gpu_device, dtype):
+    """The multi-workgroup half-sweep kernel behind nns.slab.SlabPressure: (1) one rank through SlabPressure == the
+    oracle's red-black solve (bitwise + same sweep count in float64); (2) a hand-made 3-slab split in one process (odd
+    row offsets, so the colour parity depends on gi0) with halo copies == the same."""
+    import torch
+    import torch.distributed as dist
+    from nns import ops
+    from nns.slab import SlabPressure
+    from oracle import chorin_fd as O
+    rng = np.random.default_rng(77)
+    T = np.dtype(dtype).type
+    nx, ny, beta, cap, stol = 301, 517, 1.5, 25, 5e-6
+    dx, dy = 1.0 / nx, 1.0 / ny
+    C = (rng.standard_normal((nx, ny)) * 0.1).astype(dtype)
+    p0 = (rng.standard_normal((nx, ny)) * 0.01).astype(dtype)
+    ref = p0.copy(); prev = ref.copy(); err, sweeps = 1, 0
+    while err > stol and sweeps < cap:
+        O.sor_sweep_redblack(ref, C, T(dx), T(dy), T(beta))
+        err = np.max(np.abs(ref - prev)); prev = ref.copy(); sweeps += 1
+
+    def check(got, done=None):
+        if dtype == "float64":
+            assert np.array_equal(got, ref)
+            assert done is None or done == sweeps
+        else:
+            assert rel_l2(got, ref) < 1e-4
+
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29919', rank=0, world_size=1)
+        created = True
+    try:
+        s = SlabPressure(nx, ny, dx, dy, beta, tol=stol)
+        p = torch.as_tensor(p0.copy(), device="cuda")
+        done, e = s.solve_(p, torch.as_tensor(C, device="cuda"), cap)
+        check(p.cpu().numpy(), done)
+        if dtype == "float64":
+            assert e == err
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+    cuts = [0, 101, 198, nx]                                               # slabs of 101, 97, 103 rows: gi0 = 0, 100, 197
+    slabs, Cs, gi0s = [], [], []
+    for r in range(3):
+        lo, hi = cuts[r] - (r > 0), cuts[r + 1] + (r < 2)
+        slabs.append(torch.as_tensor(p0[lo:hi].copy(), device="cuda")); Cs.append(torch.as_tensor(C[lo:hi].copy(), device="cuda")); gi0s.append(lo)
+    ebuf = torch.zeros(1, dtype=slabs[0].dtype, device="cuda")
+    for _ in range(sweeps):
+        for colour in (0, 1):
+            for r in range(2):                                             # halo refresh: what SlabPressure._exchange does over the ring
+                slabs[r][-1].copy_(slabs[r + 1][1]); slabs[r + 1][0].copy_(slabs[r][-2])
+            for r in range(3):
+                ops.fd_sor_redblack_halfsweep_(slabs[r], Cs[r], ebuf, gi0s[r], colour, dx, dy, beta)
+    got = torch.cat([slabs[0][:-1], slabs[1][1:-1], slabs[2][1:]]).cpu().numpy()
+    check(got)
+
+
 def test_cavity_with_corrected_options(gpu_device):
     """The cavity driver with advection='corrected', pressure_solver='redblack' against the oracle run with the same
     options (float64, 1e-9); the defaults still reproduce the reference."""

@@ -100,3 +100,68 @@ def test_split_oracle_passes_equal_full_oracle():
 
 def test_world_size_one_degenerates_to_local(tmp_path):
     mp.spawn(_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sharded red-black pressure solve (nns.slab.SlabPressure): halo exchange per half-sweep + all-reduce(max) per sweep
+# ------------------------------------------------------------------------------------------------------------------
+PNX, PNY, PBETA, PCAP = 27, 14, 1.5, 60
+
+
+class OracleSor(object):
+    """CPU stand-in for HipSorCompute (tests only): one colour of oracle.chorin_fd.sor_sweep_redblack on the slab."""
+
+    def halfsweep(self, p, C, err, gi0, colour, dx, dy, beta):
+        a = p.numpy()
+        nxl, ny = a.shape
+        I, J = np.meshgrid(np.arange(1, nxl - 1), np.arange(1, ny - 1), indexing='ij')
+        m = ((I + gi0 + J) % 2) == colour
+        i, j = I[m], J[m]
+        c = C.numpy()
+        new = (beta * (dy**2 * a[i + 1, j] + dy**2 * a[i - 1, j] + dx**2 * a[i, j + 1] + dx**2 * a[i, j - 1] - c[i, j]) / (2 * dx**2 + 2 * dy**2)
+               + (1 - beta) * a[i, j])
+        if new.size:
+            err[0] = max(float(err[0]), float(np.max(np.abs(new - a[i, j]))))
+        a[i, j] = new
+        return err
+
+    def err_value(self, err):
+        return err
+
+
+def pressure_problem():
+    rng = np.random.default_rng(5)
+    return 0.01 * rng.standard_normal((PNX, PNY)), 0.1 * rng.standard_normal((PNX, PNY))
+
+
+def _pworker(rank, world, port, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nns.slab import SlabPressure
+        p0, C = pressure_problem()
+        s = SlabPressure(PNX, PNY, 1.0 / PNX, 1.0 / PNY, PBETA, tol=1e-9, compute=OracleSor())
+        pl = torch.from_numpy(np.ascontiguousarray(s.local_rows(p0)))
+        done, err = s.solve_(pl, torch.from_numpy(np.ascontiguousarray(s.local_rows(C))), PCAP)
+        np.save(os.path.join(out, 'p%d.npy' % rank), pl.numpy())
+        np.save(os.path.join(out, 'i%d.npy' % rank), np.array([done, err, s.lo, s.hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2, 4])
+def test_slab_pressure_redblack(world, tmp_path):
+    """The sharded red-black solve is bitwise the single-process one (uneven row split 27 = 7+7+7+6, early stop off)."""
+    from oracle import chorin_fd as O
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_pworker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p0, C = pressure_problem()
+    ref = p0.copy(); err, sweeps, prev = 1.0, 0, p0.copy()
+    while err > 1e-9 and sweeps < PCAP:
+        O.sor_sweep_redblack(ref, C, 1.0 / PNX, 1.0 / PNY, PBETA)
+        err = np.max(np.abs(ref - prev)); prev = ref.copy(); sweeps += 1
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), 'p%d.npy' % r)) for r in range(world)])
+    info = [np.load(os.path.join(str(tmp_path), 'i%d.npy' % r)) for r in range(world)]
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    assert all(int(i[0]) == sweeps and i[1] == err for i in info)
+    assert [int(i[2]) for i in info] == [sum(len(x) for x in np.array_split(np.arange(PNX), world)[:r]) for r in range(world)]
