@@ -141,6 +141,15 @@ int nns_fd_sor_redblack_halfsweep_f32(float* p, const float* C, void* err_bits, 
 int nns_fd_sor_redblack_halfsweep_f64(double* p, const double* C, void* err_bits, int nxl, int ny, int gi0, int colour,
                                       double dx, double dy, double beta, void* stream);
 
+/* spatial_coarsen (src/utils.py:13-60): block means over agg_x x agg_y cells of the [nt][nx][ny] sequences u, v, p into
+ * [nt][nx/agg_x][ny/agg_y], one launch for the three fields.  The add order of numpy.mean (pairwise) is reproduced, so
+ * float64 results are bit-identical to the reference's.  jfill = number of coarse COLUMNS the reference fills per row:
+ * its column loop runs to ny // agg_x (:49), cells beyond stay 0; pass ny / agg_y for the plain block mean. */
+int nns_coarsen_f32(const float* u, const float* v, const float* p, float* cu, float* cv, float* cp, int nt, int nx, int ny,
+                    int agg_x, int agg_y, int jfill, void* stream);
+int nns_coarsen_f64(const double* u, const double* v, const double* p, double* cu, double* cv, double* cp, int nt, int nx, int ny,
+                    int agg_x, int agg_y, int jfill, void* stream);
+
 /* _correction_step (:204-210): u = u* - dt/(2dx) d0x p, v = v* - dt/(2dy) d0y p; edges from u*. */
 int nns_fd_correction_f32(const float* ui, const float* vi, const float* p, float* u, float* v,
                           int batch, int nx, int ny, double dt, double dx, double dy, void* stream);

@@ -45,6 +45,7 @@ _DUAL = {
     'nns_fd_direct_update': [_P] * 5 + [_I] * 3 + [_D] * 5 + [_P],
     'nns_fd_residual': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_fd_residual_bwd': [_P] * 10 + [_I] * 3 + [_D] * 5 + [_I, _P],
+    'nns_coarsen': [_P] * 6 + [_I] * 6 + [_P],
 }
 _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],

@@ -152,6 +152,25 @@ def fd_correction(ui, vi, p, dt, dx, dy):
     return u, v
 
 
+def coarsen(u, v, p, agg_x, agg_y, jfill=None):
+    """Block means of the [T, nx, ny] device sequences u, v, p over agg_x x agg_y cells (nns_coarsen_*).
+    jfill: coarse columns filled per row (the rest are 0); default ny / agg_y."""
+    if not (u.dim() == 3 and u.shape == v.shape == p.shape and u.dtype == v.dtype == p.dtype and u.is_cuda and v.is_cuda and p.is_cuda):
+        raise ValueError("coarsen: u, v, p must be device tensors of one [T, nx, ny] shape and dtype")
+    if u.dtype not in (torch.float32, torch.float64):
+        raise TypeError("coarsen: float32 or float64 fields")
+    if not (u.is_contiguous() and v.is_contiguous() and p.is_contiguous()):
+        raise ValueError("coarsen: contiguous tensors required")
+    T, nx, ny = u.shape
+    if agg_x < 1 or agg_y < 1 or nx % agg_x or ny % agg_y:
+        raise ValueError("coarsen: nx=%d, ny=%d must be multiples of agg_x=%d, agg_y=%d" % (nx, ny, agg_x, agg_y))
+    out = [torch.empty(T, nx // agg_x, ny // agg_y, dtype=u.dtype, device=u.device) for _ in range(3)]
+    suf = '_f32' if u.dtype == torch.float32 else '_f64'
+    _call('nns_coarsen', suf, _p(u), _p(v), _p(p), _p(out[0]), _p(out[1]), _p(out[2]), T, nx, ny, int(agg_x), int(agg_y),
+          ny // agg_y if jfill is None else int(jfill), _stream())
+    return tuple(out)
+
+
 # ----------------------------------------------------------------------------- direct_fd
 def fd_build_b(u, v, dt, dx, dy, rho):
     suf, (B, nx, ny) = _chk(u, v)

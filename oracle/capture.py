@@ -369,7 +369,37 @@ def worker_rnn():
     np.savez_compressed(os.path.join(GOLD, 'neural_rnn.npz'), **out)
 
 
-WORKERS = dict(rnn=worker_rnn, boundary=worker_boundary, chorin_fd=worker_chorin_fd, direct_fd=worker_direct_fd,
+def worker_utils():
+    """spatial_coarsen: src/utils.py:13-60.  Cases: the default 4x4 blocks, 3x3 = 9
+    (pairwise-sum leaf + tail), 2x2 = 4 (short running sum), 16x16 = 256 (one split of the pairwise recursion), and
+    agg_x > agg_y (8x2, 5x3, 3x2, 4x2), where the reference's column loop (ny // agg_x) leaves cells at 0; agg_x < agg_y
+    overruns the coarse array (recorded as the error the reference raises)."""
+    from src.utils import spatial_coarsen
+    rng = np.random.default_rng(0)
+    out = {}
+    for tag, (T, nx, ny, ax, ay) in dict(a=(3, 16, 24, 4, 4), b=(2, 32, 8, 8, 2), c=(2, 20, 9, 5, 3), d=(2, 9, 8, 3, 2),
+                                         e=(1, 32, 48, 16, 16), f=(2, 16, 16, 4, 2), g=(2, 9, 12, 3, 3), h=(2, 6, 10, 2, 2)).items():
+        X, Y = np.meshgrid(np.linspace(0, 2, nx), np.linspace(0, 2, ny), indexing='ij')
+        f = [np.stack([smooth_field(rng, nx, ny) for _ in range(T)]) for _ in range(3)]
+        nX, nY, cu, cv, cp = spatial_coarsen(X, Y, f[0], f[1], f[2], agg_x=ax, agg_y=ay)
+        out[tag + '_shape'] = np.array([T, nx, ny, ax, ay])
+        out[tag + '_u'], out[tag + '_v'], out[tag + '_p'] = f
+        out[tag + '_X'], out[tag + '_Y'], out[tag + '_cu'], out[tag + '_cv'], out[tag + '_cp'] = nX, nY, cu, cv, cp
+    # agg_x < agg_y: the column loop overruns the coarse array -> the reference raises
+    X, Y = np.meshgrid(np.linspace(0, 2, 8), np.linspace(0, 2, 8), indexing='ij')
+    z = np.zeros((1, 8, 8))
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            spatial_coarsen(X, Y, z, z, z, agg_x=2, agg_y=4)
+        out['overrun_error'] = np.array('none')
+    except Exception as e:                                         # noqa: BLE001 -- recording which error the reference raises
+        out['overrun_error'] = np.array(type(e).__name__)
+    np.savez_compressed(os.path.join(GOLD, 'utils_coarsen.npz'), **out)
+
+
+WORKERS = dict(utils=worker_utils, rnn=worker_rnn, boundary=worker_boundary, chorin_fd=worker_chorin_fd, direct_fd=worker_direct_fd,
                chorin_spectral=worker_chorin_spectral, neural=worker_neural)
 
 
