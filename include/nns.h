@@ -126,10 +126,15 @@ int nns_fd_predictor_adi_corrected_f64(const double* un, const double* vn, const
                                        double dt, double dx, double dy, double nu, void* stream);
 /* Red-black SOR: the update formula, relaxation factor, stopping rule (max|p - pPrev| <= tol) and sweep cap of
  * nns_fd_sor, with the points of one colour ((i + j) even, then odd) relaxed in parallel: two barriers per sweep
- * instead of nx + ny fronts.  Same info layout; no workspace.  oracle: get_pressure_redblack (bitwise). */
-int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, int batch, int nx, int ny,
+ * instead of nx + ny fronts.  Same info layout.  oracle: get_pressure_redblack (bitwise).
+ * Grids whose p and C fit LDS (2 nx ny elements <= 150 KB) are solved by one workgroup each, work may be NULL.
+ * Larger grids run every half-sweep as a chip-wide launch: all 2 max_sweeps launches are enqueued at once and turn
+ * themselves off on the device once a sweep's error is <= tol (no host round trip); they need
+ * nns_fd_sor_redblack_workspace(batch, nx, ny, elem_size, max_sweeps) bytes of device memory in `work` (0 = fits LDS). */
+size_t nns_fd_sor_redblack_workspace(int batch, int nx, int ny, int elem_size, int max_sweeps);
+int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, void* work, int batch, int nx, int ny,
                             double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
-int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, int batch, int nx, int ny,
+int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny,
                             double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
 
 /* One red-black HALF-sweep on a row slab p[nxl][ny] whose rows 0 and nxl-1 are halo / boundary rows (not written);

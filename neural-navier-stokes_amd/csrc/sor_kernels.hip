@@ -139,12 +139,13 @@ int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double
 // Red-black SOR (oracle: get_pressure_redblack): the same update formula, relaxation
 // factor, stopping rule and sweep cap as the reference's loop, but points with (i + j) even are relaxed first, then the
 // odd ones.  A half-sweep only reads the other colour, so it is fully parallel: one workgroup per grid, every thread
-// a few points, two barriers per sweep (the lexicographic order needs nx + ny fronts per sweep).  p and C stay in LDS
-// when they fit; the error reduction is exact (max), so the result is bitwise the oracle's (no FMA contraction).
+// a few points, two barriers per sweep (the lexicographic order needs nx + ny fronts per sweep), p and C in LDS.  Grids
+// that do not fit LDS take the chained chip-wide half-sweep launches further down (sor_redblack).  The error reduction
+// is exact (max), so either way the result is bitwise the oracle's (no FMA contraction).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kRbThreads = 1024;
 
-template <typename T, bool IN_LDS>
+template <typename T>
 __global__ __launch_bounds__(kRbThreads) void sor_redblack_kernel(T* __restrict__ p, const T* __restrict__ C, T* __restrict__ info,
                                                                    int nx, int ny, int max_sweeps, SorK<T> k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -153,12 +154,9 @@ __global__ __launch_bounds__(kRbThreads) void sor_redblack_kernel(T* __restrict_
     const int tid = threadIdx.x, n = nx * ny;
     T* pg = p + (size_t)blockIdx.x * n;
     const T* cg = C + (size_t)blockIdx.x * n;
-    T* pw = IN_LDS ? reinterpret_cast<T*>(smem) : pg;
-    const T* cw = IN_LDS ? reinterpret_cast<const T*>(smem) + n : cg;
-    if (IN_LDS) {
-        T* cl = reinterpret_cast<T*>(smem) + n;
-        for (int c = tid; c < n; c += kRbThreads) { pw[c] = pg[c]; cl[c] = cg[c]; }
-    }
+    T* pw = reinterpret_cast<T*>(smem);                   // p and C live in LDS for the whole solve
+    T* cw = pw + n;
+    for (int c = tid; c < n; c += kRbThreads) { pw[c] = pg[c]; cw[c] = cg[c]; }
     __syncthreads();
     const int mx = nx - 2, my = ny - 2, hw = (my + 1) / 2, half = mx * hw;     // points of one colour: <= hw per interior row
     T err = (T)1;
@@ -193,30 +191,9 @@ __global__ __launch_bounds__(kRbThreads) void sor_redblack_kernel(T* __restrict_
         ++done;
     }
     __syncthreads();
-    if (IN_LDS) for (int c = tid; c < n; c += kRbThreads) pg[c] = pw[c];
+    for (int c = tid; c < n; c += kRbThreads) pg[c] = pw[c];
     if (tid == 0) { info[2 * blockIdx.x] = (T)done; info[2 * blockIdx.x + 1] = err; }
 }
-
-template <typename T>
-int sor_redblack(T* p, const T* C, T* info, int batch, int nx, int ny, double dx, double dy, double beta, double tol, int max_sweeps, hipStream_t s) {
-    if (!p || !C || !info || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
-        return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
-    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
-    const size_t lds = 2 * (size_t)nx * ny * sizeof(T);
-    if (lds <= 150 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_redblack_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor_redblack: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr = true;
-        }
-        hipLaunchKernelGGL((sor_redblack_kernel<T, true>), dim3(batch), dim3(kRbThreads), lds, s, p, C, info, nx, ny, max_sweeps, k);
-    } else {
-        hipLaunchKernelGGL((sor_redblack_kernel<T, false>), dim3(batch), dim3(kRbThreads), 0, s, p, C, info, nx, ny, max_sweeps, k);
-    }
-    return check_launch("fd_sor_redblack");
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // One red-black HALF-sweep on a row slab (the opt-in sharded pressure solve).  p is
@@ -229,11 +206,28 @@ template <typename T> struct BitsOf;
 template <> struct BitsOf<float> { using U = unsigned int; };
 template <> struct BitsOf<double> { using U = unsigned long long; };
 
+// Chained use (red-black solve of grids too large for LDS, sor_redblack below): blockIdx.z = grid of the batch; the
+// launches of ALL sweeps are enqueued up front and each one decides on the device whether it still has to run:
+// sweep s is active iff the previous sweep's error (prev_bits, null for "always") is > tol -- the reference's
+// `while err > tol` -- so no host round trip per sweep.  A skipped sweep marks its own slot NaN, which keeps every
+// later sweep skipped whatever the sign of tol.
 template <typename T>
 __global__ __launch_bounds__(256) void sor_rb_halfsweep_kernel(T* __restrict__ p, const T* __restrict__ C, typename BitsOf<T>::U* __restrict__ err_bits,
+                                                                const typename BitsOf<T>::U* __restrict__ prev_bits, long slot_stride,
                                                                 int nxl, int ny, int gi0, int colour, SorK<T> k) {
     using U = typename BitsOf<T>::U;
     __shared__ T wave_e[256 / kWave];
+    const size_t b = blockIdx.z;
+    p += b * (size_t)nxl * ny;
+    C += b * (size_t)nxl * ny;
+    err_bits += b * slot_stride;
+    if (prev_bits) {
+        const T prev = __builtin_bit_cast(T, prev_bits[b * slot_stride]);
+        if (!(prev > k.tol)) {
+            if (colour == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *err_bits = ~(U)0 >> 1;    // quiet NaN pattern
+            return;
+        }
+    }
     const int hw = (ny - 2 + 1) / 2;
     const int q = blockIdx.x * 256 + threadIdx.x;
     T e = (T)0;
@@ -262,15 +256,74 @@ __global__ __launch_bounds__(256) void sor_rb_halfsweep_kernel(T* __restrict__ p
 }
 
 template <typename T>
+void launch_halfsweep(T* p, const T* C, typename BitsOf<T>::U* err, const typename BitsOf<T>::U* prev, long slot_stride, int batch,
+                      int nxl, int ny, int gi0, int colour, const SorK<T>& k, hipStream_t s) {
+    const int hw = (ny - 2 + 1) / 2;
+    const int gx = (hw + 255) / 256, gy = std::min(nxl - 2, std::max(1, 2048 / gx));
+    hipLaunchKernelGGL(sor_rb_halfsweep_kernel<T>, dim3(gx, gy, batch), dim3(256), 0, s, p, C, err, prev, slot_stride, nxl, ny, gi0, colour, k);
+}
+
+template <typename T>
 int sor_rb_halfsweep(T* p, const T* C, void* err_bits, int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, hipStream_t s) {
     if (!p || !C || !err_bits || nxl < 3 || ny < 3 || (colour != 0 && colour != 1) || gi0 < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack_halfsweep: bad args (nxl=%d ny=%d gi0=%d colour=%d)", nxl, ny, gi0, colour);
     SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)0};
-    const int hw = (ny - 2 + 1) / 2;
-    const int gx = (hw + 255) / 256, gy = std::min(nxl - 2, std::max(1, 2048 / gx));
-    hipLaunchKernelGGL(sor_rb_halfsweep_kernel<T>, dim3(gx, gy), dim3(256), 0, s, p, C,
-                       static_cast<typename BitsOf<T>::U*>(err_bits), nxl, ny, gi0, colour, k);
+    launch_halfsweep<T>(p, C, static_cast<typename BitsOf<T>::U*>(err_bits), nullptr, 0, 1, nxl, ny, gi0, colour, k, s);
     return check_launch("fd_sor_redblack_halfsweep");
+}
+
+// slots[b][0] = the bit pattern of 1 (the reference's initial err, :183), slots[b][1 .. cap] = 0
+template <typename T>
+__global__ void sor_rb_init_kernel(typename BitsOf<T>::U* __restrict__ slots, long n, int per_grid) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = (i % per_grid == 0) ? __builtin_bit_cast(typename BitsOf<T>::U, (T)1) : 0;
+}
+
+// info[b] = (sweeps done, err of the last sweep done): walk the chain exactly as the host loop would
+template <typename T>
+__global__ void sor_rb_finish_kernel(const typename BitsOf<T>::U* __restrict__ slots, T* __restrict__ info, int batch, int cap, T tol) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const typename BitsOf<T>::U* sl = slots + (size_t)b * (cap + 1);
+    T err = (T)1;
+    int done = 0;
+    while (done < cap && err > tol) { err = __builtin_bit_cast(T, sl[done + 1]); ++done; }
+    info[2 * b] = (T)done;
+    info[2 * b + 1] = err;
+}
+
+inline bool rb_fits_lds(int nx, int ny, size_t elem) { return 2 * (size_t)nx * ny * elem <= 150 * 1024; }
+
+template <typename T>
+int sor_redblack(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double dx, double dy, double beta, double tol, int max_sweeps, hipStream_t s) {
+    if (!p || !C || !info || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
+        return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
+    if (rb_fits_lds(nx, ny, sizeof(T))) {
+        const size_t lds = 2 * (size_t)nx * ny * sizeof(T);
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_redblack_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor_redblack: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
+        hipLaunchKernelGGL((sor_redblack_kernel<T>), dim3(batch), dim3(kRbThreads), lds, s, p, C, info, nx, ny, max_sweeps, k);
+        return check_launch("fd_sor_redblack");
+    }
+    // Larger grids: every half-sweep is a chip-wide launch (one workgroup would leave 255 CUs idle); all 2 * max_sweeps
+    // launches are enqueued at once and switch themselves off on the device once a sweep's error is <= tol.
+    using U = typename BitsOf<T>::U;
+    if (!work) return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack: a %dx%d grid needs the workspace of nns_fd_sor_redblack_workspace", nx, ny);
+    if (batch > 65535) return fail(NNS_ERR_UNSUPPORTED, "fd_sor_redblack: batch %d of large grids exceeds the launch grid (65535)", batch);
+    U* slots = static_cast<U*>(work);
+    const int per = max_sweeps + 1;
+    const long nslots = (long)batch * per;
+    hipLaunchKernelGGL(sor_rb_init_kernel<T>, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, slots, nslots, per);
+    for (int sw = 0; sw < max_sweeps; ++sw)
+        for (int colour = 0; colour < 2; ++colour)
+            launch_halfsweep<T>(p, C, slots + sw + 1, slots + sw, per, batch, nx, ny, 0, colour, k, s);
+    hipLaunchKernelGGL(sor_rb_finish_kernel<T>, dim3((batch + 255) / 256), dim3(256), 0, s, slots, info, batch, max_sweeps, (T)tol);
+    return check_launch("fd_sor_redblack");
 }
 
 }  // namespace
@@ -288,13 +341,17 @@ NNS_API int nns_fd_sor_f64(double* p, const double* C, double* info, void* work,
     return sor<double>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
 }
 
-NNS_API int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, int batch, int nx, int ny, double dx, double dy,
-                                    double beta, double tol, int max_sweeps, void* stream) {
-    return sor_redblack<float>(p, C, info, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+NNS_API size_t nns_fd_sor_redblack_workspace(int batch, int nx, int ny, int elem_size, int max_sweeps) {
+    if (batch < 1 || nx < 3 || ny < 3 || (elem_size != 4 && elem_size != 8) || max_sweeps < 0) return 0;
+    return rb_fits_lds(nx, ny, (size_t)elem_size) ? 0 : (size_t)batch * (max_sweeps + 1) * elem_size;
 }
-NNS_API int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, int batch, int nx, int ny, double dx, double dy,
+NNS_API int nns_fd_sor_redblack_f32(float* p, const float* C, float* info, void* work, int batch, int nx, int ny, double dx, double dy,
                                     double beta, double tol, int max_sweeps, void* stream) {
-    return sor_redblack<double>(p, C, info, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+    return sor_redblack<float>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_redblack_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny, double dx, double dy,
+                                    double beta, double tol, int max_sweeps, void* stream) {
+    return sor_redblack<double>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
 }
 
 NNS_API int nns_fd_sor_redblack_halfsweep_f32(float* p, const float* C, void* err_bits, int nxl, int ny, int gi0, int colour,

@@ -37,7 +37,7 @@ _DUAL = {
     'nns_fd_predictor_adi_corrected': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_pressure_rhs': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_sor': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
-    'nns_fd_sor_redblack': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_fd_sor_redblack': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_sor_redblack_halfsweep': [_P] * 3 + [_I] * 4 + [_D] * 3 + [_P],
     'nns_fd_correction': [_P] * 5 + [_I] * 3 + [_D] * 3 + [_P],
     'nns_fd_build_b': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
@@ -71,11 +71,12 @@ _SINGLE = {
     'nns_basis_loss_bwd_f32': [_P] * 3 + [C.c_float] + [_P] * 2 + [_I] * 4 + [_P],
     'nns_fd_predictor_adi_workspace': [_I, _I, _I, _I],
     'nns_fd_sor_workspace': [_I, _I, _I, _I],
+    'nns_fd_sor_redblack_workspace': [_I, _I, _I, _I, _I],
     'nns_device_info': [C.c_char_p, _I, C.POINTER(_I), C.POINTER(_SZ)],
     'nns_version': [],
     'nns_last_error': [],
 }
-_RESTYPES = {'nns_ode_mlp_bwd_workspace': _SZ, 'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_last_error': C.c_char_p}
+_RESTYPES = {'nns_ode_mlp_bwd_workspace': _SZ, 'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_fd_sor_redblack_workspace': _SZ, 'nns_last_error': C.c_char_p}
 
 
 def exported_names():

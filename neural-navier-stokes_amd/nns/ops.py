@@ -131,7 +131,10 @@ def fd_sor_redblack_(p, C, dx, dy, beta, tol, max_sweeps):
     """Red-black SOR, in place on p (an option of the build).  Returns the device info tensor [batch, 2]."""
     suf, (B, nx, ny) = _chk(p, C)
     info = torch.empty(B, 2, dtype=p.dtype, device=p.device)
-    _call('nns_fd_sor_redblack', suf, _p(p), _p(C), _p(info), B, nx, ny, dx, dy, beta, tol, int(max_sweeps), _stream())
+    nbytes = _lib.lib().nns_fd_sor_redblack_workspace(B, nx, ny, p.element_size(), int(max_sweeps))     # 0: the grids fit LDS
+    work = torch.empty(nbytes // p.element_size(), dtype=p.dtype, device=p.device) if nbytes else None
+    _call('nns_fd_sor_redblack', suf, _p(p), _p(C), _p(info), _p(work) if nbytes else None, B, nx, ny, dx, dy, beta, tol,
+          int(max_sweeps), _stream())
     return info
 
 

@@ -20,4 +20,17 @@ for n in (1024, 4096):
         torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 50
         b = p.element_size()
         out['n%d_%s' % (n, str(dt).split('.')[1])] = dict(us_per_sweep=1e6 * t, GBs_algorithmic=3 * n * n * b / t / 1e9)
+# the whole chained solve (nns_fd_sor_redblack on a grid that does not fit LDS): 49 sweeps, tolerance never reached
+for n in (1024,):
+    for dt in (torch.float32, torch.float64):
+        p0 = torch.randn(1, n, n, device='cuda', dtype=dt) * 0.01
+        C = torch.randn(1, n, n, device='cuda', dtype=dt) * 0.1
+        def solve():
+            p = p0.clone()
+            return ops.fd_sor_redblack_(p, C, 1.0 / n, 1.0 / n, 1.5, 5e-6, 49)
+        for _ in range(3): solve()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): info = solve()
+        torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+        out['solve49_n%d_%s' % (n, str(dt).split('.')[1])] = dict(ms=1e3 * t, sweeps=float(info[0, 0]))
 print(json.dumps(out))
