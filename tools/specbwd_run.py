@@ -1,0 +1,18 @@
+"""Developer helper: the fused spectral residual backward at 1024^2 x 64 (for rocprofv3 / A-B timing)."""
+import os, sys, json, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'neural-navier-stokes_amd')):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+from nns import ops
+n, B = 1024, 64
+f = [torch.randn(B, n, n, device='cuda') for _ in range(5)]
+L = 2 * np.pi
+for _ in range(3):
+    ops.spec_residual_bwd(*f, 1e-3, L, L, 1.0, L / 1000)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    ops.spec_residual_bwd(*f, 1e-3, L, L, 1.0, L / 1000)
+torch.cuda.synchronize()
+print(json.dumps(dict(spec_bwd_ms=1e3 * (time.perf_counter() - t0) / 20)))
