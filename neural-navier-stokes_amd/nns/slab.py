@@ -159,45 +159,157 @@ class SlabPressure(object):
         """This rank's rows of a global [nx, ny] array."""
         return full[self.lo:self.hi]
 
-    def _exchange(self, slab):
-        """slab: [nloc + has_up + has_down, ny]; refresh its halo rows from the neighbours' edge rows."""
+    def exchange_halo(self, *slabs):
+        """Refresh the halo rows of the given slabs ([nloc + has_up + has_down, ny] each) from the neighbours' edge rows:
+        ONE message per direction carrying all the fields (no wrap: the domain is not periodic)."""
+        if self.P == 1:
+            return
+        up, down = self.has_up, self.has_down
         reqs = []
-        first = slab[1 if self.has_up else 0].contiguous()
-        last = slab[-2 if self.has_down else -1].contiguous()
-        top = torch.empty_like(first) if self.has_up else None
-        bot = torch.empty_like(last) if self.has_down else None
-        if self.has_up:
+        if up:
+            first = torch.stack([a[1] for a in slabs])
+            top = torch.empty_like(first)
             reqs += [dist.isend(first, self.rank - 1, group=self.group), dist.irecv(top, self.rank - 1, group=self.group)]
-        if self.has_down:
+        if down:
+            last = torch.stack([a[-2] for a in slabs])
+            bot = torch.empty_like(last)
             reqs += [dist.isend(last, self.rank + 1, group=self.group), dist.irecv(bot, self.rank + 1, group=self.group)]
         for q in reqs:
             q.wait()
-        if self.has_up:
-            slab[0].copy_(top)
-        if self.has_down:
-            slab[-1].copy_(bot)
+        for i, a in enumerate(slabs):
+            if up:
+                a[0].copy_(top[i])
+            if down:
+                a[-1].copy_(bot[i])
 
-    def solve_(self, p_loc, C_loc, max_sweeps):
-        """p_loc, C_loc: this rank's rows [hi - lo, ny] (p is updated in place).  Returns (sweeps done, last err)."""
-        up, down = int(self.has_up), int(self.has_down)
-        nloc = self.hi - self.lo
-        slab = torch.zeros(nloc + up + down, self.ny, dtype=p_loc.dtype, device=p_loc.device)
-        cs = torch.zeros_like(slab)
-        slab[up:up + nloc].copy_(p_loc)
-        cs[up:up + nloc].copy_(C_loc)
-        gi0 = self.lo - up                                   # global row of slab row 0
-        err_buf = torch.zeros(1, dtype=p_loc.dtype, device=p_loc.device)
+    def to_slab(self, rows):
+        """Owned rows [hi - lo, ny] -> working slab with (zeroed) halo rows."""
+        up = int(self.has_up)
+        slab = torch.zeros(rows.shape[0] + up + int(self.has_down), self.ny, dtype=rows.dtype, device=rows.device)
+        slab[up:up + rows.shape[0]].copy_(rows)
+        return slab
+
+    def owned(self, slab):
+        """View of the owned rows of a working slab."""
+        up = int(self.has_up)
+        return slab[up:up + (self.hi - self.lo)]
+
+    def solve_slab_(self, slab, cs, max_sweeps):
+        """Red-black solve in place on the working slab (halo rows are refreshed here).  Returns (sweeps, last err)."""
+        gi0 = self.lo - int(self.has_up)                      # global row of slab row 0
+        err_buf = torch.zeros(1, dtype=slab.dtype, device=slab.device)
         err, done = 1.0, 0
         while done < max_sweeps and err > self.tol:
             err_buf.zero_()
             for colour in (0, 1):
-                if self.P > 1:
-                    self._exchange(slab)
+                self.exchange_halo(slab)
                 self.compute.halfsweep(slab, cs, err_buf, gi0, colour, self.dx, self.dy, self.beta)
             e = self.compute.err_value(err_buf).clone()
             if self.P > 1:
                 dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)
             err = float(e.item())
             done += 1
-        p_loc.copy_(slab[up:up + nloc])
         return done, err
+
+    def solve_(self, p_loc, C_loc, max_sweeps):
+        """p_loc, C_loc: this rank's rows [hi - lo, ny] (p is updated in place).  Returns (sweeps done, last err)."""
+        slab, cs = self.to_slab(p_loc), self.to_slab(C_loc)
+        done, err = self.solve_slab_(slab, cs, max_sweeps)
+        p_loc.copy_(self.owned(slab))
+        return done, err
+
+
+class HipChorinCompute(HipSorCompute):
+    """Operator back-end of SlabChorinFD: the HIP kernels of the single-GPU chorin_fd mirror, applied to a row slab."""
+
+    def predictor(self, un, vn, un1, vn1, dt, dx, dy, nu, corrected):
+        from . import ops
+        f = ops.fd_predictor_explicit_corrected if corrected else ops.fd_predictor_explicit
+        return f(un, vn, un1, vn1, dt, dx, dy, nu)
+
+    def bc_apply_(self, A, bcs):
+        from . import ops
+        if bcs:
+            ops.bc_apply_(A, bcs)
+        return A
+
+    def rhs(self, ui, vi, dt, dx, dy, rho):
+        from . import ops
+        return ops.fd_pressure_rhs(ui, vi, dt, dx, dy, rho)
+
+    def correction(self, ui, vi, p, dt, dx, dy):
+        from . import ops
+        return ops.fd_correction(ui, vi, p, dt, dx, dy)
+
+
+def _bc_tuple(b):
+    return tuple(b) if isinstance(b, (tuple, list)) else (b.type, b.boundary, b.value, b.dx, b.dy)
+
+
+class SlabChorinFD(object):
+    """The chorin_fd projection step (src/chorin_fd/simulate.py:212-234, explicit predictor) on ONE [nx, ny] cavity grid
+    sharded by rows over the ranks -- SURVEY.md section 8 (e), rows 1-2 ("cavity (non-periodic) = same without wrap";
+    "opt-in red-black shards like Jacobi").  The pressure solve is the red-black option (the reference's lexicographic
+    order is sequential across slabs and does not shard); everything else is the reference's step:
+
+        exchange (u, v)^n halos [done at the end of the previous step]
+        predictor on the slab -> u*, v*      (interior rows = owned rows; halo / boundary rows copy u^n as in the kernel)
+        u / v boundary conditions            ('left' only on the first rank, 'right' only on the last, columns everywhere;
+                                              list order kept, so corners resolve as in the single-process run)
+        exchange (u*, v*) halos              (the RHS differences backwards along x)
+        C = RHS;  red-black SOR (SlabPressure.solve_slab_: halo exchange per half-sweep, all-reduce(max) per sweep)
+        p boundary conditions;  exchange p halos   (the correction differences p centrally along x)
+        correction -> u, v^{n+1};  exchange their halos
+
+    = 3 packed neighbour exchanges per step outside the pressure solve.  In float64 the owned rows are bitwise those of
+    the single-process run with pressure_solver='redblack' (same kernels, same operation order per point)."""
+
+    def __init__(self, u_bc, v_bc, p_bc, nit, nx, ny, dt, rho, nu, beta, advection='reference', group=None, compute=None):
+        assert advection in ['reference', 'corrected']
+        self.compute = compute if compute is not None else HipChorinCompute()
+        self.nx, self.ny, self.dt, self.rho, self.nu, self.beta, self.nit = nx, ny, dt, rho, nu, beta, nit
+        self.dx, self.dy = 2. / (nx - 1), 2. / (ny - 1)                    # src/chorin_fd/simulate.py:58
+        self.corrected = advection == 'corrected'
+        self.press = SlabPressure(nx, ny, self.dx, self.dy, beta, tol=5e-6, group=group, compute=self.compute)
+        keep = lambda b: not ((b[1] == 'left' and self.press.has_up) or (b[1] == 'right' and self.press.has_down))
+        self.u_bc, self.v_bc, self.p_bc = ([b for b in map(_bc_tuple, l) if keep(b)] for l in (u_bc, v_bc, p_bc))
+        self.last_sor = None
+
+    def init_slabs(self, u_ic, v_ic, p_ic):
+        """Global initial fields (every rank passes the same arrays) -> this rank's working slabs with the boundary
+        conditions applied and the halos filled (src/chorin_fd/simulate.py:236-249)."""
+        sp = self.press
+        slabs = [sp.to_slab(sp.local_rows(a)) for a in (u_ic, v_ic, p_ic)]
+        for a, bc in zip(slabs, (self.u_bc, self.v_bc, self.p_bc)):
+            self.compute.bc_apply_(a, bc)
+        sp.exchange_halo(*slabs)
+        return slabs
+
+    def step(self, un, vn, un1, vn1, p):
+        """One step on working slabs (halos of un, vn, un1, vn1 valid on entry).  p is updated in place; returns (u, v, p)
+        with valid halos."""
+        c, sp = self.compute, self.press
+        ui, vi = c.predictor(un, vn, un1, vn1, self.dt, self.dx, self.dy, self.nu, self.corrected)
+        c.bc_apply_(ui, self.u_bc)
+        c.bc_apply_(vi, self.v_bc)
+        sp.exchange_halo(ui, vi)
+        C = c.rhs(ui, vi, self.dt, self.dx, self.dy, self.rho)
+        self.last_sor = sp.solve_slab_(p, C, max(int(self.nit) - 1, 0))
+        c.bc_apply_(p, self.p_bc)
+        sp.exchange_halo(p)
+        u, v = c.correction(ui, vi, p, self.dt, self.dx, self.dy)
+        sp.exchange_halo(u, v)
+        return u, v, p
+
+    def simulate(self, u_ic, v_ic, p_ic, nt):
+        """nt steps from the global initial fields; returns this rank's OWNED rows of the trajectory,
+        three tensors [nt, hi - lo, ny] (rank order = row order: concatenate along axis 1 for the global fields)."""
+        u, v, p = self.init_slabs(u_ic, v_ic, p_ic)
+        u1, v1 = u.clone(), v.clone()                                       # first step: u^{-1} = u^0 (:256)
+        sp = self.press
+        us, vs, ps = [], [], []
+        for _ in range(nt):
+            nu_, nv_, p = self.step(u, v, u1, v1, p)
+            u1, v1, u, v = u, v, nu_, nv_
+            us.append(sp.owned(u).clone()), vs.append(sp.owned(v).clone()), ps.append(sp.owned(p).clone())
+        return torch.stack(us), torch.stack(vs), torch.stack(ps)

@@ -431,6 +431,39 @@ def test_sharded_redblack_halfsweep(gpu_device, dtype):
     check(got)
 
 
+def test_slab_chorin_fd_single_rank_uses_hip_backend(gpu_device):
+    """nns.slab.SlabChorinFD with its default (HIP) operators on one rank == the single-GPU driver with
+    pressure_solver='redblack' (bitwise, float64) and the oracle (1e-9); halo logic: tests/test_slab_gloo.py."""
+    import torch
+    import torch.distributed as dist
+    from nns.chorin_fd import NavierStokesSystem
+    from nns.slab import SlabChorinFD
+    from oracle import chorin_fd as O
+    from oracle.boundary import cavity_bcs
+    n, nt = 48, 6
+    dx = dy = 2. / (n - 1)
+    u_bc, v_bc, p_bc = cavity_bcs(dx, dy)
+    z = np.zeros((n, n))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29921', rank=0, world_size=1)
+        created = True
+    try:
+        for adv in ('reference', 'corrected'):
+            s = SlabChorinFD(u_bc, v_bc, p_bc, 50, n, n, 1e-3, 1.0, 0.05, 1.25, advection=adv)
+            us, vs, ps = s.simulate(*[torch.as_tensor(z.copy(), device='cuda') for _ in range(3)], nt)
+            u, v, p = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=nt, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.05,
+                                         beta=1.25, method='explicit', advection=adv, pressure_solver='redblack').simulate()
+            for g, r in zip((us, vs, ps), (u, v, p)):
+                assert np.array_equal(g.cpu().numpy(), r), adv
+            ur, vr, pr = O.simulate(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt, 50, 1e-3, 1, 0.05, 1.25, 'explicit',
+                                    advection=adv, pressure_solver='redblack')
+            assert np.abs(us.cpu().numpy() - ur).max() < 1e-9 and np.abs(ps.cpu().numpy() - pr).max() < 1e-9
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_cavity_with_corrected_options(gpu_device):
     """The cavity driver with advection='corrected', pressure_solver='redblack' against the oracle run with the same
     options (float64, 1e-9); the defaults still reproduce the reference."""

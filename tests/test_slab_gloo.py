@@ -165,3 +165,73 @@ def test_slab_pressure_redblack(world, tmp_path):
     assert got.shape == ref.shape and np.array_equal(got, ref)
     assert all(int(i[0]) == sweeps and i[1] == err for i in info)
     assert [int(i[2]) for i in info] == [sum(len(x) for x in np.array_split(np.arange(PNX), world)[:r]) for r in range(world)]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the whole chorin_fd cavity step sharded by rows (nns.slab.SlabChorinFD): bitwise the single-process oracle run
+# ------------------------------------------------------------------------------------------------------------------
+CNX, CNY, CNT, CNIT = 22, 17, 6, 30
+
+
+class OracleChorin(OracleSor):
+    """CPU stand-in for HipChorinCompute (tests only): the oracle's operators applied to the slab arrays."""
+
+    def predictor(self, un, vn, un1, vn1, dt, dx, dy, nu, corrected):
+        from oracle import chorin_fd as O
+        f = O.explicit_predictor_corrected if corrected else O.explicit_predictor
+        ui, vi = f(un.numpy(), vn.numpy(), un1.numpy(), vn1.numpy(), dt, dx, dy, nu)
+        return torch.from_numpy(ui), torch.from_numpy(vi)
+
+    def bc_apply_(self, A, bcs):
+        from oracle.boundary import apply_bc_list
+        apply_bc_list(A.numpy(), bcs)
+        return A
+
+    def rhs(self, ui, vi, dt, dx, dy, rho):
+        from oracle import chorin_fd as O
+        return torch.from_numpy(O.pressure_rhs(ui.numpy(), vi.numpy(), dt, dx, dy, rho))
+
+    def correction(self, ui, vi, p, dt, dx, dy):
+        from oracle import chorin_fd as O
+        u, v = O.correction(ui.numpy(), vi.numpy(), p.numpy(), dt, dx, dy)
+        return torch.from_numpy(u), torch.from_numpy(v)
+
+
+def cavity_problem():
+    from oracle.boundary import cavity_bcs
+    rng = np.random.default_rng(9)
+    dx, dy = 2. / (CNX - 1), 2. / (CNY - 1)
+    ics = [0.05 * rng.standard_normal((CNX, CNY)) for _ in range(3)]        # non-trivial ICs: the BCs must overwrite the edges
+    return ics, cavity_bcs(dx, dy)
+
+
+def _cworker(rank, world, port, out, advection):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nns.slab import SlabChorinFD
+        ics, (u_bc, v_bc, p_bc) = cavity_problem()
+        s = SlabChorinFD(u_bc, v_bc, p_bc, CNIT, CNX, CNY, 1e-3, 1.0, 0.05, 1.25, advection=advection, compute=OracleChorin())
+        us, vs, ps = s.simulate(*[torch.from_numpy(a.copy()) for a in ics], CNT)
+        np.savez(os.path.join(out, 'c%d.npz' % rank), u=us.numpy(), v=vs.numpy(), p=ps.numpy(), sor=np.array(s.last_sor))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,advection', [(1, 'reference'), (2, 'reference'), (4, 'corrected'), (3, 'reference')])
+def test_slab_chorin_fd_cavity(world, advection, tmp_path):
+    """Row-sharded cavity run == oracle.simulate(pressure_solver='redblack') on the whole grid, bitwise (float64): the
+    lid on 'right' lives on the last rank only, Neumann 'left' / 'right' pressure rows on the edge ranks, uneven splits
+    (22 rows over 3 and 4 ranks)."""
+    from oracle import chorin_fd as O
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_cworker, args=(world, port, str(tmp_path), advection), nprocs=world, join=True)
+    ics, (u_bc, v_bc, p_bc) = cavity_problem()
+    ur, vr, pr = O.simulate(*[a.copy() for a in ics], u_bc, v_bc, p_bc, CNT, CNIT, 1e-3, 1.0, 0.05, 1.25, 'explicit',
+                            advection=advection, pressure_solver='redblack')
+    parts = [np.load(os.path.join(str(tmp_path), 'c%d.npz' % r)) for r in range(world)]
+    for name, ref in (('u', ur), ('v', vr), ('p', pr)):
+        got = np.concatenate([d[name] for d in parts], axis=1)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    assert len({tuple(d['sor']) for d in parts}) == 1                      # every rank saw the same sweep count and err
+    assert np.abs(ur[-1]).max() > 1e-3                                      # the lid drives a flow
