@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include "nns_common.h"
 
 #ifndef NNS_DFT_SB
 #define NNS_DFT_SB 1      // scheduling barriers between the dft4 groups of a float64 dft16 (bounds register pressure)
@@ -30,12 +31,6 @@
 namespace nns {
 
 template <typename T> struct C2 { T x, y; };
-
-// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, I1)
-template <int I0, int I1, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
-}
 
 template <typename T> __device__ __forceinline__ C2<T> operator+(C2<T> a, C2<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> __device__ __forceinline__ C2<T> operator-(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }

@@ -488,11 +488,255 @@ __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict
     }
 }
 
-struct LossGeom { int TC, rows_per_split, nsplit, ppt; dim3 grid; size_t lds; };
+// ------------------------------------------------------------------------------------------------------------------
+// The same pass for the usual shape (K <= 16, P >= 4096), built around what bounds it on gfx950: arithmetic.  Per
+// element the backward needs 3 K FMAs (prediction, gbasis, gcoeff partial); a wave64 v_fma_f32 issues in 4 cycles but
+// v_pk_fma_f32 does two lanes' worth in 4.3 (tools/valu_rate_bench.hip), so
+//   * every FMA of the hot loop is a v_pk_fma_f32; the packed dimension is the coefficient index (see the kernel);
+//   * the coefficients are padded to KMAX in {4, 8, 10, 12, 16} -- the smallest that holds K -- not to 16: at the
+//     reference's K = 10 the padding was 37 % of the FMAs;
+//   * the per-row gcoeff partials of 32 / KMAX rows (32 values per lane) go through ONE transposing butterfly within each
+//     32-lane half (lane l ends with the half's total of value l mod 32) and leave in one atomic wave-instruction.  Its
+//     top level -- 16 of the 31 exchange steps -- is v_permlane16_swap_b32 (one VALU instruction swaps the odd / even
+//     16-lane rows of two registers in place) instead of two selects and a ds_bpermute per step; the lower levels are
+//     DPP moves.  (Inline asm: this ROCm's __builtin_amdgcn_permlane{16,32}_swap returns the same register for both
+//     results.)  NNS_PK_PART = 64 selects the 64-value butterfly over all lanes (v_permlane32_swap on top): it needs
+//     254+ registers and measured slower (one wave per SIMD or spills).
+// BASELINE config 5 (T = 8192, K = 10, 3 x 256^2): loss backward 4.34 -> 2.92 ms, forward 1.59 -> 1.26 ms.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef NNS_PK_PART
+#define NNS_PK_PART 32               // values per butterfly: 64 (all lanes, TT = 64 / KMAX rows) or 32 (per 32-lane half)
+#endif
+constexpr int kPart64 = NNS_PK_PART;
+
+// Four independent register pairs per asm block.  A VALU write of an operand within the two preceding issue slots is a
+// hazard for these instructions and the compiler does not see inside the block: one leading s_nop 1 covers all four.
+#define NNS_SWAP4(INSN)                                                                                              \
+    asm volatile("s_nop 1\n\t" INSN " %0, %1\n\t" INSN " %2, %3\n\t" INSN " %4, %5\n\t" INSN " %6, %7"               \
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3))
+__device__ __forceinline__ void swap_halves4(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3, float& b3) {
+    NNS_SWAP4("v_permlane32_swap_b32");                                     // a.hi <-> b.lo  (32-lane halves)
+}
+__device__ __forceinline__ void swap_rows4(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3, float& b3) {
+    NNS_SWAP4("v_permlane16_swap_b32");                                     // a's odd 16-lane rows <-> b's even rows
+}
+#undef NNS_SWAP4
+// values [0, 2M) -> [0, M): a lane keeps the half whose index bit matches its lane bit and adds its partner's copy
+template <int M>
+__device__ __forceinline__ void halve64(float (&part)[kPart64], int lane) {
+    if constexpr (M == 32 || M == 16) {
+#pragma unroll
+        for (int e = 0; e < M; e += 4) {
+            if constexpr (M == 32) swap_halves4(part[e], part[e + M], part[e + 1], part[e + 1 + M], part[e + 2], part[e + 2 + M], part[e + 3], part[e + 3 + M]);
+            else swap_rows4(part[e], part[e + M], part[e + 1], part[e + 1 + M], part[e + 2], part[e + 2 + M], part[e + 3], part[e + 3 + M]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[e + i] += part[e + i + M];
+        }
+    } else {
+        // lane ^ M within a 16-lane row as DPP moves (VALU, no LDS round trip as ds_bpermute has): quad_perm for M = 1, 2,
+        // row_ror:8 for M = 8; M = 4 takes two bank-masked row shifts (lanes with bit 2 clear read lane + 4, the others lane - 4)
+        const bool up = (lane & M) != 0;
+#pragma unroll
+        for (int e = 0; e < M; ++e) {
+            const int send = __builtin_bit_cast(int, up ? part[e] : part[e + M]);
+            const float keep = up ? part[e + M] : part[e];
+            int recv;
+            if constexpr (M == 1) recv = __builtin_amdgcn_update_dpp(0, send, 0xB1, 0xF, 0xF, false);          // quad_perm:[1,0,3,2]
+            else if constexpr (M == 2) recv = __builtin_amdgcn_update_dpp(0, send, 0x4E, 0xF, 0xF, false);     // quad_perm:[2,3,0,1]
+            else if constexpr (M == 8) recv = __builtin_amdgcn_update_dpp(0, send, 0x128, 0xF, 0xF, false);    // row_ror:8
+            else {
+                recv = __builtin_amdgcn_update_dpp(0, send, 0x104, 0xF, 0x5, false);                            // row_shl:4 -> banks 0, 2
+                recv = __builtin_amdgcn_update_dpp(recv, send, 0x114, 0xF, 0xA, false);                         // row_shr:4 -> banks 1, 3
+            }
+            part[e] = keep + __builtin_bit_cast(float, recv);
+        }
+    }
+}
+
+// time rows per group: TT1 = rows whose gcoeff partials fill one butterfly (gradient modes); the loss has no butterfly and
+// takes TT0 = 2 TT1 rows (<= 8) per group -- the group is also the depth of the observation prefetch
+template <int KMAX> struct PkGeom {
+    static constexpr int TT1 = (kPart64 / KMAX) < 8 ? (kPart64 / KMAX) : 8;
+    static constexpr int TT0 = 2 * TT1 < 8 ? 2 * TT1 : 8;
+};
+inline int pk_rows_per_group(int kmax) { const int t1 = (kPart64 / kmax) < 8 ? (kPart64 / kmax) : 8; return 2 * t1 < 8 ? 2 * t1 : 8; }
+
+#ifndef NNS_PK_WAVES
+#define NNS_PK_WAVES 0              // >0: __attribute__((amdgpu_waves_per_eu(N, N))) for A/B runs; 0 = let the allocator decide
+#endif
+#if NNS_PK_WAVES
+#define NNS_PK_ATTR __attribute__((amdgpu_waves_per_eu(NNS_PK_WAVES, NNS_PK_WAVES)))
+#else
+#define NNS_PK_ATTR
+#endif
+template <int MODE, int KMAX>
+__global__ __launch_bounds__(256) NNS_PK_ATTR void basis_loss_pk_kernel(const float* __restrict__ coeff, const float* __restrict__ basis,
+                                                            const float* __restrict__ obs, double* __restrict__ sumsq,
+                                                            float* __restrict__ gcoeff, float* __restrict__ gbasis, float scale,
+                                                            int T, int K, int C, int P, int TC, int rows_per_split, int nsplit) {
+    static_assert(KMAX % 2 == 0 && KMAX <= 16, "coefficient PAIRS");
+    constexpr int NP = 4, K2 = KMAX / 2;                               // pixels per thread, coefficient pairs
+    // rows per (prefetch) group and per butterfly.  (Prefetching two butterflies ahead in the gradient modes -- TT = TT0 --
+    // measured the same 3.0 ms at 254 registers instead of 190.)
+    constexpr int RB = PkGeom<KMAX>::TT1, TT = MODE == 0 ? PkGeom<KMAX>::TT0 : RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* cw = reinterpret_cast<float*>(smem_raw);                    // [TC][KMAX], zero-padded (no k < K guard in the hot loop)
+    const int c = blockIdx.y, tid = threadIdx.x, lane = tid % kWave;
+    const int pbase = blockIdx.x * 1024 + tid;                         // pixels pbase + 256 i, i = 0..3
+    const int t_lo = blockIdx.z * rows_per_split, t_hi = min(T, t_lo + rows_per_split);
+    // The packed dimension is the COEFFICIENT index: fk[i][q] = (basis[2q], basis[2q+1]) at pixel i.  A row's coefficient
+    // pairs then come straight out of LDS as float2 -- no splat -- and the gcoeff partial of a pixel quad is a chain
+    // of 4 packed FMAs that ends as the pair (k = 2q, 2q + 1) itself, no horizontal add; only the 4 per-pixel residuals
+    // are splat.  (Packing pixel pairs instead cost 3 v_mov per 2 FMAs to build the coefficient splats.)
+    v2f fk[NP][K2], gb[NP][K2];
+    int pix[NP];
+    float okm[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const bool ok = pbase + 256 * i < P;
+        pix[i] = ok ? pbase + 256 * i : P - 1;                         // clamped: loads need no mask
+        okm[i] = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < K2; ++q) {
+            const float b0 = (ok && 2 * q < K) ? basis[((size_t)(2 * q) * C + c) * P + pix[i]] : 0.f;
+            const float b1 = (ok && 2 * q + 1 < K) ? basis[((size_t)(2 * q + 1) * C + c) * P + pix[i]] : 0.f;
+            fk[i][q] = (v2f){b0, b1};
+            gb[i][q] = (v2f){0.f, 0.f};
+        }
+    }
+    double local = 0.0;
+    float part[kPart64];
+#pragma unroll
+    for (int e = 0; e < kPart64; ++e) part[e] = 0.f;
+    auto flush_part = [&](int t_first) {
+        if constexpr (kPart64 == 64) halve64<32>(part, lane);
+        halve64<16>(part, lane); halve64<8>(part, lane);
+        halve64<4>(part, lane); halve64<2>(part, lane); halve64<1>(part, lane);
+        const int v = lane % kPart64, tt = v / KMAX, k = v % KMAX;     // lane l holds the total of value l mod kPart64 = tt * KMAX + k
+        if (tt < RB && k < K && t_first + tt < t_hi) atomicAdd(&gcoeff[((size_t)(t_first + tt) * K + k) * C + c], part[0]);
+#pragma unroll
+        for (int e = 0; e < kPart64; ++e) part[e] = 0.f;
+    };
+    for (int t0 = t_lo; t0 < t_hi; t0 += TC) {
+        const int tn = min(TC, t_hi - t0);
+        const int tnp = (tn + TT - 1) / TT * TT;                       // whole groups: the padding rows have zero coefficients
+        __syncthreads();
+        for (int e = tid; e < tnp * KMAX; e += 256) {
+            const int tt = e / KMAX, k = e % KMAX;
+            cw[e] = (tt < tn && k < K) ? coeff[((size_t)(t0 + tt) * K + k) * C + c] : 0.f;
+        }
+        __syncthreads();
+        // Observations are requested one whole GROUP of TT rows ahead (clamped row index: re-reading the last row is
+        // harmless).  With one row in flight per wave and two waves per SIMD the pass was latency-bound: 8 KB in
+        // flight per CU / ~1.5 us = 1.4 TB/s, which is what it measured.
+        float obn[TT][NP];
+        auto request = [&](int ttg, auto tqc) {                        // row tq of the group starting at ttg
+            constexpr int tq = decltype(tqc)::value;
+            const int tt = ttg + tq;
+            const size_t row = ((size_t)(t0 + (tt < tn ? tt : tn - 1)) * C + c) * P;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) obn[tq][i] = obs[row + pix[i]];
+        };
+        // Every pixel block adds into the SAME gcoeff[t][k][c]; each starts at its own row group and wraps around so that
+        // concurrent atomics of different blocks go to different addresses.
+        const int ngroups = tnp / TT;
+        const int g0 = MODE == 0 ? 0 : (int)(((long)blockIdx.x * ngroups) / gridDim.x);
+        static_for<0, TT>([&](auto tqc) { request(g0 * TT, tqc); });
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int gcur = g0 + gi < ngroups ? g0 + gi : g0 + gi - ngroups;
+            const int gnext = gcur + 1 < ngroups ? gcur + 1 : 0;
+            const int tt0 = gcur * TT;
+            const int ttn = gi + 1 < ngroups ? gnext * TT : tt0;      // the last prefetch re-reads this group
+            static_for<0, TT>([&](auto tqc) {
+                constexpr int tq = decltype(tqc)::value;
+                const int tt = tt0 + tq;
+                float ob[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) ob[i] = obn[tq][i];
+                request(ttn, tqc);                                     // rolling: row tq of the next group replaces it at once
+                v2f w[K2];                                             // this row's coefficient pairs, read once
+#pragma unroll
+                for (int q = 0; q < K2; ++q) {
+                    const float2 v = *reinterpret_cast<const float2*>(cw + tt * KMAX + 2 * q);
+                    w[q] = (v2f){v.x, v.y};
+                }
+                // No validity masks in the gradient modes: an out-of-range pixel has fk = 0, so it adds 0 to the gcoeff
+                // partials, and its gbasis column is never stored; a padding row has w = 0 (nothing into gbasis) and its
+                // gcoeff values are dropped at the atomic (row >= t_hi).  The loss (MODE 0) does need them.
+                // (loops are written chain-index innermost: the 4 / K2 independent FMA chains interleave in program
+                // order, which the scheduler keeps -- back-to-back dependent packed FMAs each cost a hazard s_nop)
+                float g[NP];
+                if constexpr (MODE != 2) {
+                    v2f pred[NP];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) pred[i] = w[0] * fk[i][0];
+#pragma unroll
+                    for (int q = 1; q < K2; ++q)
+#pragma unroll
+                        for (int i = 0; i < NP; ++i) pred[i] = __builtin_elementwise_fma(w[q], fk[i][q], pred[i]);
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) g[i] = (pred[i].x + pred[i].y) - ob[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) g[i] = ob[i];
+                }
+                if constexpr (MODE == 0) {
+                    const float rowm = tt < tn ? 1.f : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) { const float r = g[i] * (okm[i] * rowm); local += (double)r * (double)r; }
+                }
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) g[i] *= scale;
+                }
+                if constexpr (MODE != 0) {
+                    v2f sred[K2];
+#pragma unroll
+                    for (int q = 0; q < K2; ++q) sred[q] = fk[0][q] * (v2f){g[0], g[0]};
+#pragma unroll
+                    for (int i = 1; i < NP; ++i)
+#pragma unroll
+                        for (int q = 0; q < K2; ++q) sred[q] = __builtin_elementwise_fma(fk[i][q], (v2f){g[i], g[i]}, sred[q]);
+#pragma unroll
+                    for (int q = 0; q < K2; ++q) { part[(tq % RB) * KMAX + 2 * q] = sred[q].x; part[(tq % RB) * KMAX + 2 * q + 1] = sred[q].y; }
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+#pragma unroll
+                        for (int q = 0; q < K2; ++q) gb[i][q] = __builtin_elementwise_fma(w[q], (v2f){g[i], g[i]}, gb[i][q]);
+                    if constexpr (tq % RB == RB - 1) flush_part(t0 + tt0 + tq - (RB - 1));
+                }
+            });
+        }
+    }
+    if constexpr (MODE == 0) {
+        for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_down(local, o);
+        if (lane == 0) atomicAdd(sumsq, local);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int px = pbase + 256 * i;
+            if (px < P) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    if (k < K) {
+                        float* dst = &gbasis[((size_t)k * C + c) * P + px];
+                        const float val = (k & 1) ? gb[i][k / 2].y : gb[i][k / 2].x;
+                        if (nsplit > 1) atomicAdd(dst, val); else *dst = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct LossGeom { int TC, rows_per_split, nsplit, kmax; dim3 grid; size_t lds; };      // kmax = 0: the generic kernel
 inline LossGeom loss_geom(int T, int K, int C, int P) {
     LossGeom g;
-    g.ppt = (K <= 16 && P >= 4096) ? 4 : 1;                               // register budget: 2 * PPT * KMAX floats
-    const int bx = (P + 256 * g.ppt - 1) / (256 * g.ppt);
+    const bool pk = K <= 16 && P >= 4096;                                  // register budget: 2 * 4 * KMAX floats of basis / gbasis
+    g.kmax = !pk ? 0 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 10 ? 10 : K <= 12 ? 12 : 16;
+    const int ppt = pk ? 4 : 1;
+    const int bx = (P + 256 * ppt - 1) / (256 * ppt);
     const int bxy = bx * C;
     int ns = (2048 + bxy - 1) / bxy;
     const int max_ns = (T + 31) / 32;
@@ -501,11 +745,11 @@ inline LossGeom loss_geom(int T, int K, int C, int P) {
     if (ns > 65535) ns = 65535;
     g.rows_per_split = (T + ns - 1) / ns;
     g.nsplit = (T + g.rows_per_split - 1) / g.rows_per_split;
-    const int kmax = g.ppt == 4 ? 16 : kMaxK;                              // the kernel pads the coefficients to KMAX
-    const int tt = 32 / kmax;
-    int cap = 8192 / kmax;                                                 // <= 32 KB of coefficients per chunk
-    g.TC = g.rows_per_split < cap ? g.rows_per_split : cap;
-    g.TC = (g.TC + tt - 1) / tt * tt;                                      // whole groups of TT rows
+    const int kmax = pk ? g.kmax : kMaxK;                                  // the kernels pad the coefficients to KMAX
+    const int tt = pk ? pk_rows_per_group(kmax) : 32 / kmax;             // TC in whole groups (PkGeom<KMAX>::TT0, a multiple of TT1)
+    const int cap = 8192 / kmax / tt * tt;                                 // <= 32 KB of coefficients per chunk, whole groups
+    g.TC = (g.rows_per_split + tt - 1) / tt * tt;
+    if (g.TC > cap) g.TC = cap;
     g.grid = dim3(bx, C, g.nsplit);
     g.lds = (size_t)g.TC * kmax * sizeof(float);
     return g;
@@ -514,10 +758,17 @@ inline LossGeom loss_geom(int T, int K, int C, int P) {
 template <int MODE>
 void launch_loss(const LossGeom& g, hipStream_t s, const float* coeff, const float* basis, const float* obs, double* sumsq, float* gcoeff,
                  float* gbasis, float scale, int T, int K, int C, int P) {
-    if (g.ppt == 4)
-        hipLaunchKernelGGL((basis_loss_kernel<MODE, 4, 16>), g.grid, dim3(256), g.lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, g.TC, g.rows_per_split, g.nsplit);
-    else
-        hipLaunchKernelGGL((basis_loss_kernel<MODE, 1, kMaxK>), g.grid, dim3(256), g.lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, g.TC, g.rows_per_split, g.nsplit);
+#define NNS_PK(KM) hipLaunchKernelGGL((basis_loss_pk_kernel<MODE, KM>), g.grid, dim3(256), g.lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, g.TC, g.rows_per_split, g.nsplit)
+    switch (g.kmax) {
+        case 4: NNS_PK(4); break;
+        case 8: NNS_PK(8); break;
+        case 10: NNS_PK(10); break;
+        case 12: NNS_PK(12); break;
+        case 16: NNS_PK(16); break;
+        default:
+            hipLaunchKernelGGL((basis_loss_kernel<MODE, 1, kMaxK>), g.grid, dim3(256), g.lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, g.TC, g.rows_per_split, g.nsplit);
+    }
+#undef NNS_PK
 }
 
 }  // namespace

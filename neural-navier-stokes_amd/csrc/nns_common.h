@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/nns.h"
 
@@ -70,6 +71,12 @@ inline int make_bc_dev(const nns_bc_list* h, BcListDev<T>& d) {
             return fail(NNS_ERR_INVALID_ARG, "bc entry %d: kind %d / side %d invalid", i, h->kind[i], h->side[i]);
     }
     return NNS_OK;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, I1)
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
 }
 
 }  // namespace nns

@@ -309,3 +309,33 @@ def test_gru_baselines_vs_golden(gpu_device):
     assert ex.shape == (1, 4, 3 * nx * ny) and rel_l2(ex.numpy(), GR['rnn_extrapolate']) < 1e-5
     o2, _ = r(torch.randn(3, nt, 3 * nx * ny, device='cuda'))          # batches > 1 work here (the reference's .view does not)
     assert o2.shape == (3, nt, 3 * nx * ny)
+
+
+@pytest.mark.parametrize('shape', [
+    # (T, K, C, P): every coefficient padding of the packed kernel (KMAX 4, 8, 10, 12, 16), ragged pixel tails, time
+    # rows that do not fill a butterfly group, one and several time splits; and the generic kernel (K > 16, small P)
+    (37, 3, 3, 4096), (50, 7, 2, 5000), (64, 10, 3, 16384), (19, 10, 1, 4100), (41, 12, 3, 4096 + 1024 + 7),
+    (33, 16, 2, 8192), (700, 10, 3, 4096), (2, 9, 3, 65536), (23, 20, 3, 4096), (29, 10, 3, 300)])
+def test_basis_loss_kernels_direct(shape, gpu_device):
+    """nns_basis_loss_fwd / _bwd / nns_basis_expand_bwd against float64 tensor contractions (rel-L2 2e-6: float32
+    accumulation over up to 65536 pixels / 700 rows)."""
+    from nns import ops
+    T, K, C, P = shape
+    rng = np.random.default_rng(T * 131 + K)
+    coeff = rng.standard_normal((T, K, C)).astype(np.float32)
+    basis = rng.standard_normal((K, C, P)).astype(np.float32)
+    obs = rng.standard_normal((T, C, P)).astype(np.float32)
+    c64, b64, o64 = coeff.astype(np.float64), basis.astype(np.float64), obs.astype(np.float64)
+    pred = np.einsum('tkc,kcp->tcp', c64, b64)
+    d = [torch.as_tensor(a, device='cuda') for a in (coeff, basis, obs)]
+    ss = float(ops.basis_loss_fwd(*d).item())
+    assert abs(ss - np.sum((pred - o64)**2)) < 1e-6 * np.sum((pred - o64)**2)
+    scale = 0.37
+    g = scale * (pred - o64)
+    gc, gb = ops.basis_loss_bwd(*d, scale)
+    assert rel_l2(gc.cpu().numpy(), np.einsum('tcp,kcp->tkc', g, b64)) < 2e-6
+    assert rel_l2(gb.cpu().numpy(), np.einsum('tcp,tkc->kcp', g, c64)) < 2e-6
+    gc2, gb2 = ops.basis_expand_bwd(d[0], d[1], d[2])                      # upstream gradient = obs
+    assert rel_l2(gc2.cpu().numpy(), np.einsum('tcp,kcp->tkc', o64, b64)) < 2e-6
+    assert rel_l2(gb2.cpu().numpy(), np.einsum('tcp,tkc->kcp', o64, c64)) < 2e-6
+    assert torch.allclose(ops.basis_expand(d[0], d[1]).cpu(), torch.as_tensor(pred, dtype=torch.float32), rtol=1e-4, atol=1e-4)
