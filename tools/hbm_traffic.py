@@ -1,0 +1,18 @@
+"""Developer helper: HBM bytes per launch of the headline kernels from the two PMC passes of tools/profile_round.sh
+(gpurun_out/pmc_FETCH_SIZE_TAG, pmc_WRITE_SIZE_TAG) -> profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
+Counters are in KiB; on gfx950 FETCH_SIZE counts half of the fetched bytes (x2, /opt/skills/guides/MI355X_MICROARCH.md)."""
+import csv, glob, collections, json, os, sys
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+val = {}
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(root, 'gpurun_out', 'pmc_%s_%s' % (c, tag), '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass') if n in r['Kernel_Name']), None)
+            if s and r['Counter_Name'] == c:
+                acc[s].append(float(r['Counter_Value']))
+    val[c] = {k: sum(v) / len(v) for k, v in acc.items()}
+out = {k: (2 * val['FETCH_SIZE'][k] + val['WRITE_SIZE'][k]) * 1024 for k in val['FETCH_SIZE']}
+json.dump(out, open(os.path.join(root, 'profiles', 'hbm_traffic.json'), 'w'), indent=1)
+print(out)
