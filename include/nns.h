@@ -88,6 +88,17 @@ int nns_fd_predictor_adi_f64(const double* un, const double* vn, const double* u
                              double* ui, double* vi, double* work, int batch, int nx, int ny,
                              double dt, double dx, double dy, double nu, void* stream);
 
+/* The same predictor on a COLUMN slab [nx][nyl] of a square nx x nx grid (halo / boundary columns 0 and nyl-1 are copied
+ * from un like any edge): both solves run along axis 0, so column slabs need no communication for them -- the
+ * multi-GPU form of the ADI step (nns/slab.py: SlabChorinFD(method='semi_implicit')).  Identical arithmetic; only
+ * the nx == ny check is waived. */
+int nns_fd_predictor_adi_colslab_f32(const float* un, const float* vn, const float* un1, const float* vn1,
+                                     float* ui, float* vi, float* work, int batch, int nx, int nyl,
+                                     double dt, double dx, double dy, double nu, void* stream);
+int nns_fd_predictor_adi_colslab_f64(const double* un, const double* vn, const double* un1, const double* vn1,
+                                     double* ui, double* vi, double* work, int batch, int nx, int nyl,
+                                     double dt, double dx, double dy, double nu, void* stream);
+
 /* dx2dy2C of _get_pressure (:186-188): backward-difference divergence RHS, zero on the edge. */
 int nns_fd_pressure_rhs_f32(const float* ui, const float* vi, float* C, int batch, int nx, int ny,
                             double dt, double dx, double dy, double rho, void* stream);

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kTX) void predictor_explicit_kernel(const T* __rest
 
 template <typename T>
 int predictor_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T* vi, int batch, int nx, int ny,
-                       double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false) {
+                       double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false, bool column_slab = false) {
     if (!un || !vn || !un1 || !vn1 || !ui || !vi || !field_args_ok(batch, nx, ny))
         return fail(NNS_ERR_INVALID_ARG, "fd_predictor_explicit: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
     PredK<T> k{(T)dt, (T)(2 * dx), (T)(2 * dy), (T)(dx * dx), (T)(dy * dy), (T)(dt * nu)};
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(64) void adi_ysolve_kernel(const T* __restrict__ un
 
 template <typename T>
 int predictor_adi(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T* vi, T* work, int batch, int nx, int ny,
-                  double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false) {
+                  double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false, bool column_slab = false) {
     if (!un || !vn || !un1 || !vn1 || !ui || !vi || !work || !field_args_ok(batch, nx, ny))
         return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
-    if (!corrected && nx != ny) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: the reference's second ADI solve acts along axis 0 (src/chorin_fd/simulate.py:159), which needs nx == ny (got %d x %d)", nx, ny);
+    if (!corrected && !column_slab && nx != ny) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: the reference's second ADI solve acts along axis 0 (src/chorin_fd/simulate.py:159), which needs nx == ny (got %d x %d)", nx, ny);
     if (nu == 0) return fail(NNS_ERR_INVALID_ARG, "fd_predictor_adi: nu must be non-zero (2/nu)");
     AdiK<T> k;
     k.dt = (T)dt; k.two_dx = (T)(2 * dx); k.two_dy = (T)(2 * dy); k.dx2 = (T)(dx * dx); k.dy2 = (T)(dy * dy);
@@ -589,6 +589,14 @@ NNS_API int nns_fd_predictor_adi_corrected_f64(const double* un, const double* v
 NNS_API int nns_fd_predictor_adi_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi, double* work,
                                      int batch, int nx, int ny, double dt, double dx, double dy, double nu, void* stream) {
     return predictor_adi<double>(un, vn, un1, vn1, ui, vi, work, batch, nx, ny, dt, dx, dy, nu, S(stream));
+}
+NNS_API int nns_fd_predictor_adi_colslab_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* ui, float* vi, float* work,
+                                             int batch, int nx, int nyl, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_adi<float>(un, vn, un1, vn1, ui, vi, work, batch, nx, nyl, dt, dx, dy, nu, S(stream), false, true);
+}
+NNS_API int nns_fd_predictor_adi_colslab_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* ui, double* vi, double* work,
+                                             int batch, int nx, int nyl, double dt, double dx, double dy, double nu, void* stream) {
+    return predictor_adi<double>(un, vn, un1, vn1, ui, vi, work, batch, nx, nyl, dt, dx, dy, nu, S(stream), false, true);
 }
 
 NNS_API int nns_fd_pressure_rhs_f32(const float* ui, const float* vi, float* C, int batch, int nx, int ny, double dt, double dx, double dy, double rho, void* stream) {

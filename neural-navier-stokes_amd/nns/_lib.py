@@ -35,6 +35,7 @@ _DUAL = {
     'nns_fd_predictor_explicit_corrected': [_P] * 6 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_predictor_adi': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_predictor_adi_corrected': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
+    'nns_fd_predictor_adi_colslab': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_pressure_rhs': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_sor': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_sor_redblack': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],

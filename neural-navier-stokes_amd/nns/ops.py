@@ -99,13 +99,16 @@ def fd_predictor_explicit_corrected(un, vn, un1, vn1, dt, dx, dy, nu):
     return ui, vi
 
 
-def fd_predictor_adi(un, vn, un1, vn1, dt, dx, dy, nu, corrected=False):
-    """corrected=True: the second ADI solve runs along axis 1 (an option of the build; nx != ny allowed)."""
+def fd_predictor_adi(un, vn, un1, vn1, dt, dx, dy, nu, corrected=False, column_slab=False):
+    """corrected=True: the second ADI solve runs along axis 1 (an option of the build; nx != ny allowed).
+    column_slab=True: the inputs are a column slab [nx, nyl] of a square grid (nns.slab.SlabChorinFD)."""
+    if corrected and column_slab:
+        raise ValueError("fd_predictor_adi: column slabs are for the reference ADI (both solves along axis 0)")
     suf, (B, nx, ny) = _chk(un, vn, un1, vn1)
     ui, vi = torch.empty_like(un), torch.empty_like(vn)
     nbytes = _lib.lib().nns_fd_predictor_adi_workspace(B, nx, ny, un.element_size())
     work = torch.empty(nbytes // un.element_size(), dtype=un.dtype, device=un.device)
-    _call('nns_fd_predictor_adi_corrected' if corrected else 'nns_fd_predictor_adi', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(ui), _p(vi), _p(work), B, nx, ny,
+    _call('nns_fd_predictor_adi_corrected' if corrected else 'nns_fd_predictor_adi_colslab' if column_slab else 'nns_fd_predictor_adi', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(ui), _p(vi), _p(work), B, nx, ny,
           dt, dx, dy, nu, _stream())
     return ui, vi
 

@@ -142,13 +142,18 @@ class SlabPressure(object):
     max|p - pPrev|.  Same formula, relaxation factor, stopping rule and sweep cap as nns_fd_sor_redblack; the result is
     bitwise the single-process red-black solve (a half-sweep only reads the other colour)."""
 
-    def __init__(self, nx, ny, dx, dy, beta, tol=5e-6, group=None, compute=None):
+    def __init__(self, nx, ny, dx, dy, beta, tol=5e-6, group=None, compute=None, axis=0):
+        """axis = 0: row slabs (the description above).  axis = 1: COLUMN slabs -- columns [lo, hi) of ny with halo
+        columns; "rows" below then reads "columns" (the halo lines are strided, so they are packed for the exchange)."""
+        assert axis in (0, 1)
+        self.axis = axis
         self.group = group
         self.P = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        if nx < 3 * self.P:
-            raise ValueError("need at least 3 rows per rank (nx=%d over %d ranks)" % (nx, self.P))
-        base, rem = divmod(nx, self.P)
+        n_split = nx if axis == 0 else ny
+        if n_split < 3 * self.P:
+            raise ValueError("need at least 3 lines per rank (%d over %d ranks)" % (n_split, self.P))
+        base, rem = divmod(n_split, self.P)
         counts = [base + (1 if r < rem else 0) for r in range(self.P)]
         self.lo = sum(counts[:self.rank]); self.hi = self.lo + counts[self.rank]
         self.nx, self.ny, self.dx, self.dy, self.beta, self.tol = nx, ny, dx, dy, beta, tol
@@ -156,8 +161,12 @@ class SlabPressure(object):
         self.compute = compute if compute is not None else HipSorCompute()
 
     def local_rows(self, full):
-        """This rank's rows of a global [nx, ny] array."""
-        return full[self.lo:self.hi]
+        """This rank's rows (axis 0) or columns (axis 1) of a global [nx, ny] array."""
+        return full[self.lo:self.hi] if self.axis == 0 else full[:, self.lo:self.hi]
+
+    def _line(self, a, i):
+        """Line i along the split axis (a view): row i, or column i."""
+        return a[i] if self.axis == 0 else a[:, i]
 
     def exchange_halo(self, *slabs):
         """Refresh the halo rows of the given slabs ([nloc + has_up + has_down, ny] each) from the neighbours' edge rows:
@@ -167,36 +176,40 @@ class SlabPressure(object):
         up, down = self.has_up, self.has_down
         reqs = []
         if up:
-            first = torch.stack([a[1] for a in slabs])
+            first = torch.stack([self._line(a, 1) for a in slabs])
             top = torch.empty_like(first)
             reqs += [dist.isend(first, self.rank - 1, group=self.group), dist.irecv(top, self.rank - 1, group=self.group)]
         if down:
-            last = torch.stack([a[-2] for a in slabs])
+            last = torch.stack([self._line(a, -2) for a in slabs])
             bot = torch.empty_like(last)
             reqs += [dist.isend(last, self.rank + 1, group=self.group), dist.irecv(bot, self.rank + 1, group=self.group)]
         for q in reqs:
             q.wait()
         for i, a in enumerate(slabs):
             if up:
-                a[0].copy_(top[i])
+                self._line(a, 0).copy_(top[i])
             if down:
-                a[-1].copy_(bot[i])
+                self._line(a, -1).copy_(bot[i])
 
     def to_slab(self, rows):
         """Owned rows [hi - lo, ny] -> working slab with (zeroed) halo rows."""
-        up = int(self.has_up)
-        slab = torch.zeros(rows.shape[0] + up + int(self.has_down), self.ny, dtype=rows.dtype, device=rows.device)
-        slab[up:up + rows.shape[0]].copy_(rows)
+        up, halo = int(self.has_up), int(self.has_up) + int(self.has_down)
+        if self.axis == 0:
+            slab = torch.zeros(rows.shape[0] + halo, self.ny, dtype=rows.dtype, device=rows.device)
+            slab[up:up + rows.shape[0]].copy_(rows)
+        else:
+            slab = torch.zeros(self.nx, rows.shape[1] + halo, dtype=rows.dtype, device=rows.device)
+            slab[:, up:up + rows.shape[1]].copy_(rows)
         return slab
 
     def owned(self, slab):
         """View of the owned rows of a working slab."""
         up = int(self.has_up)
-        return slab[up:up + (self.hi - self.lo)]
+        return slab[up:up + (self.hi - self.lo)] if self.axis == 0 else slab[:, up:up + (self.hi - self.lo)]
 
     def solve_slab_(self, slab, cs, max_sweeps):
         """Red-black solve in place on the working slab (halo rows are refreshed here).  Returns (sweeps, last err)."""
-        gi0 = self.lo - int(self.has_up)                      # global row of slab row 0
+        gi0 = self.lo - int(self.has_up)                      # global index of slab line 0: the colour of a point is (offset + i + j) % 2
         err_buf = torch.zeros(1, dtype=slab.dtype, device=slab.device)
         err, done = 1.0, 0
         while done < max_sweeps and err > self.tol:
@@ -226,6 +239,10 @@ class HipChorinCompute(HipSorCompute):
         from . import ops
         f = ops.fd_predictor_explicit_corrected if corrected else ops.fd_predictor_explicit
         return f(un, vn, un1, vn1, dt, dx, dy, nu)
+
+    def predictor_adi(self, un, vn, un1, vn1, dt, dx, dy, nu):
+        from . import ops
+        return ops.fd_predictor_adi(un, vn, un1, vn1, dt, dx, dy, nu, column_slab=True)
 
     def bc_apply_(self, A, bcs):
         from . import ops
@@ -264,14 +281,24 @@ class SlabChorinFD(object):
     = 3 packed neighbour exchanges per step outside the pressure solve.  In float64 the owned rows are bitwise those of
     the single-process run with pressure_solver='redblack' (same kernels, same operation order per point)."""
 
-    def __init__(self, u_bc, v_bc, p_bc, nit, nx, ny, dt, rho, nu, beta, advection='reference', group=None, compute=None):
-        assert advection in ['reference', 'corrected']
+    def __init__(self, u_bc, v_bc, p_bc, nit, nx, ny, dt, rho, nu, beta, advection='reference', group=None, compute=None,
+                 method='explicit'):
+        """method='semi_implicit' (the reference's ADI predictor, :93-167): both of its tridiagonal solves run along axis
+        0, so the grid is split into COLUMN slabs and the solves need no communication at all (SURVEY.md section 8 (e),
+        ADI row); the halo columns serve the explicit terms.  Then 'bottom' / 'top' are the sides owned by the first /
+        last rank.  It needs nx == ny globally, as in the reference."""
+        assert advection in ['reference', 'corrected'] and method in ['explicit', 'semi_implicit']
+        if method == 'semi_implicit' and (advection != 'reference' or nx != ny):
+            raise ValueError("semi_implicit slabs: the reference ADI (advection='reference') on a square grid")
+        self.method = method
+        axis = 1 if method == 'semi_implicit' else 0
         self.compute = compute if compute is not None else HipChorinCompute()
         self.nx, self.ny, self.dt, self.rho, self.nu, self.beta, self.nit = nx, ny, dt, rho, nu, beta, nit
         self.dx, self.dy = 2. / (nx - 1), 2. / (ny - 1)                    # src/chorin_fd/simulate.py:58
         self.corrected = advection == 'corrected'
-        self.press = SlabPressure(nx, ny, self.dx, self.dy, beta, tol=5e-6, group=group, compute=self.compute)
-        keep = lambda b: not ((b[1] == 'left' and self.press.has_up) or (b[1] == 'right' and self.press.has_down))
+        self.press = SlabPressure(nx, ny, self.dx, self.dy, beta, tol=5e-6, group=group, compute=self.compute, axis=axis)
+        lo_side, hi_side = ('left', 'right') if axis == 0 else ('bottom', 'top')       # A[0, :], A[-1, :] / A[:, 0], A[:, -1]
+        keep = lambda b: not ((b[1] == lo_side and self.press.has_up) or (b[1] == hi_side and self.press.has_down))
         self.u_bc, self.v_bc, self.p_bc = ([b for b in map(_bc_tuple, l) if keep(b)] for l in (u_bc, v_bc, p_bc))
         self.last_sor = None
 
@@ -289,7 +316,10 @@ class SlabChorinFD(object):
         """One step on working slabs (halos of un, vn, un1, vn1 valid on entry).  p is updated in place; returns (u, v, p)
         with valid halos."""
         c, sp = self.compute, self.press
-        ui, vi = c.predictor(un, vn, un1, vn1, self.dt, self.dx, self.dy, self.nu, self.corrected)
+        if self.method == 'semi_implicit':
+            ui, vi = c.predictor_adi(un, vn, un1, vn1, self.dt, self.dx, self.dy, self.nu)
+        else:
+            ui, vi = c.predictor(un, vn, un1, vn1, self.dt, self.dx, self.dy, self.nu, self.corrected)
         c.bc_apply_(ui, self.u_bc)
         c.bc_apply_(vi, self.v_bc)
         sp.exchange_halo(ui, vi)
@@ -302,8 +332,9 @@ class SlabChorinFD(object):
         return u, v, p
 
     def simulate(self, u_ic, v_ic, p_ic, nt):
-        """nt steps from the global initial fields; returns this rank's OWNED rows of the trajectory,
-        three tensors [nt, hi - lo, ny] (rank order = row order: concatenate along axis 1 for the global fields)."""
+        """nt steps from the global initial fields; returns this rank's OWNED rows (columns for semi_implicit) of the
+        trajectory, three tensors [nt, hi - lo, ny] ([nt, nx, hi - lo]); rank order = line order: concatenate along
+        axis 1 (2) for the global fields."""
         u, v, p = self.init_slabs(u_ic, v_ic, p_ic)
         u1, v1 = u.clone(), v.clone()                                       # first step: u^{-1} = u^0 (:256)
         sp = self.press

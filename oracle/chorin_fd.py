@@ -133,10 +133,12 @@ def thomas_const(lo, di, up, rhs):
     return x
 
 
-def semi_implicit_predictor(u, v, u1, v1, dt, dx, dy, nu):
+def semi_implicit_predictor(u, v, u1, v1, dt, dx, dy, nu, column_slab=False):
     """AB2 advection (correct axes) + Crank-Nicolson diffusion by ADI.
-    src/chorin_fd/simulate.py:93-167.  Both solves act along axis 0 (quirk)."""
-    assert u.shape[-1] == u.shape[-2], "reference semi_implicit needs nx == ny (:159,:165)"
+    src/chorin_fd/simulate.py:93-167.  Both solves act along axis 0 (quirk).
+    column_slab=True: the arrays are a column slab [nx, nyl] of a square grid (tests of the sharded step): the same
+    arithmetic, the systems along axis 0 have the full size nx - 2; only the squareness assert is waived."""
+    assert column_slab or u.shape[-1] == u.shape[-2], "reference semi_implicit needs nx == ny (:159,:165)"
     un, vn, un1, vn1 = u, v, u1, v1
     ut, vt = u.copy(), v.copy()
     ui, vi = u.copy(), v.copy()

@@ -464,6 +464,52 @@ def test_slab_chorin_fd_single_rank_uses_hip_backend(gpu_device):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_adi_predictor_on_column_slab(gpu_device, dtype):
+    """nns_fd_predictor_adi_colslab_*: the reference ADI on a column slab [nx, nyl] of a square grid equals the same
+    columns of the full-grid result (the solves run along axis 0) and the oracle on the slab; and SlabChorinFD
+    (method='semi_implicit') on one rank equals the single-GPU driver with the red-black pressure option."""
+    import torch
+    import torch.distributed as dist
+    from nns import ops
+    from nns.chorin_fd import NavierStokesSystem
+    from nns.slab import SlabChorinFD
+    from oracle import chorin_fd as O
+    from oracle.boundary import cavity_bcs
+    rng = np.random.default_rng(8)
+    n = 40
+    f = [rng.standard_normal((n, n)).astype(dtype) for _ in range(4)]
+    dt, h, nu = 1e-2, 2. / (n - 1), 0.2
+    tol = 1e-12 if dtype == "float64" else 3e-5
+    full = ops.fd_predictor_adi(*[torch.as_tensor(a, device="cuda") for a in f], dt, h, h, nu)
+    lo, hi = 9, 26                                                        # slab = columns 9..25: owned 10..24 + one halo column each side
+    sl = [np.ascontiguousarray(a[:, lo:hi]) for a in f]
+    got = ops.fd_predictor_adi(*[torch.as_tensor(a, device="cuda") for a in sl], dt, h, h, nu, column_slab=True)
+    ref = O.semi_implicit_predictor(*[a.astype(np.float64) for a in sl], dt, h, h, nu, column_slab=True)
+    for g, r, fu in zip(got, ref, full):
+        assert rel_l2(g.cpu().numpy(), r) < tol
+        assert torch.equal(g[:, 1:-1], fu[:, lo + 1:hi - 1])             # interior columns: bitwise the full-grid run
+    with pytest.raises(RuntimeError):
+        ops.fd_predictor_adi(*[torch.as_tensor(a, device="cuda") for a in sl], dt, h, h, nu)      # not square, not declared a slab
+    if dtype == "float64":
+        created = False
+        if not dist.is_initialized():
+            dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29923', rank=0, world_size=1)
+            created = True
+        try:
+            u_bc, v_bc, p_bc = cavity_bcs(h, h)
+            z = np.zeros((n, n))
+            s = SlabChorinFD(u_bc, v_bc, p_bc, 50, n, n, 1e-3, 1.0, 0.05, 1.25, method='semi_implicit')
+            us, vs, ps = s.simulate(*[torch.as_tensor(z.copy(), device='cuda') for _ in range(3)], 5)
+            u, v, p = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=5, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.05,
+                                         beta=1.25, method='semi_implicit', pressure_solver='redblack').simulate()
+            for g, r in zip((us, vs, ps), (u, v, p)):
+                assert np.array_equal(g.cpu().numpy(), r)
+        finally:
+            if created:
+                dist.destroy_process_group()
+
+
 def test_cavity_with_corrected_options(gpu_device):
     """The cavity driver with advection='corrected', pressure_solver='redblack' against the oracle run with the same
     options (float64, 1e-9); the defaults still reproduce the reference."""

@@ -182,6 +182,11 @@ class OracleChorin(OracleSor):
         ui, vi = f(un.numpy(), vn.numpy(), un1.numpy(), vn1.numpy(), dt, dx, dy, nu)
         return torch.from_numpy(ui), torch.from_numpy(vi)
 
+    def predictor_adi(self, un, vn, un1, vn1, dt, dx, dy, nu):
+        from oracle import chorin_fd as O
+        ui, vi = O.semi_implicit_predictor(un.numpy(), vn.numpy(), un1.numpy(), vn1.numpy(), dt, dx, dy, nu, column_slab=True)
+        return torch.from_numpy(ui), torch.from_numpy(vi)
+
     def bc_apply_(self, A, bcs):
         from oracle.boundary import apply_bc_list
         apply_bc_list(A.numpy(), bcs)
@@ -235,3 +240,44 @@ def test_slab_chorin_fd_cavity(world, advection, tmp_path):
         assert got.shape == ref.shape and np.array_equal(got, ref), name
     assert len({tuple(d['sor']) for d in parts}) == 1                      # every rank saw the same sweep count and err
     assert np.abs(ur[-1]).max() > 1e-3                                      # the lid drives a flow
+
+
+SN = 21          # the reference's ADI needs a square grid
+
+
+def _aworker(rank, world, port, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nns.slab import SlabChorinFD
+        from oracle.boundary import cavity_bcs
+        rng = np.random.default_rng(4)
+        ics = [0.05 * rng.standard_normal((SN, SN)) for _ in range(3)]
+        h = 2. / (SN - 1)
+        u_bc, v_bc, p_bc = cavity_bcs(h, h)
+        s = SlabChorinFD(u_bc, v_bc, p_bc, CNIT, SN, SN, 1e-3, 1.0, 0.05, 1.25, method='semi_implicit', compute=OracleChorin())
+        us, vs, ps = s.simulate(*[torch.from_numpy(a.copy()) for a in ics], CNT)
+        np.savez(os.path.join(out, 'a%d.npz' % rank), u=us.numpy(), v=vs.numpy(), p=ps.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2, 4])
+def test_slab_chorin_fd_semi_implicit_column_slabs(world, tmp_path):
+    """The reference's ADI step on COLUMN slabs (both tridiagonal solves run along axis 0: no communication for them;
+    'bottom' lives on the first rank, 'top' on the last) == oracle.simulate(method='semi_implicit',
+    pressure_solver='redblack') on the whole grid, bitwise."""
+    from oracle import chorin_fd as O
+    from oracle.boundary import cavity_bcs
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_aworker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(4)
+    ics = [0.05 * rng.standard_normal((SN, SN)) for _ in range(3)]
+    h = 2. / (SN - 1)
+    u_bc, v_bc, p_bc = cavity_bcs(h, h)
+    ur, vr, pr = O.simulate(*[a.copy() for a in ics], u_bc, v_bc, p_bc, CNT, CNIT, 1e-3, 1.0, 0.05, 1.25, 'semi_implicit',
+                            pressure_solver='redblack')
+    parts = [np.load(os.path.join(str(tmp_path), 'a%d.npz' % r)) for r in range(world)]
+    for name, ref in (('u', ur), ('v', vr), ('p', pr)):
+        got = np.concatenate([d[name] for d in parts], axis=2)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
