@@ -30,13 +30,20 @@ def dup_vector_by_col(v, n):
 
 class NavierStokesSystem():
     def __init__(self, u_ic, v_ic, p_ic, u_bc, v_bc, nt=200, nit=50,
-                 nx=50, ny=50, dt=0.001, rho=1, nu=1, beta=1.25, device=None):
+                 nx=50, ny=50, dt=0.001, rho=1, nu=1, beta=1.25, device=None, matrices='reference'):
         self.u_ic, self.v_ic, self.p_ic = u_ic, v_ic, p_ic
         self.u_bc, self.v_bc = u_bc, v_bc                      # no BC needed for pressure (:44)
         self.nt, self.nit, self.dt, self.nx, self.ny = nt, nit, dt, nx, ny
         self.dx, self.dy = 2. / self.nx, 2. / self.ny          # (:48)
         self.rho, self.nu, self.beta = rho, nu, beta
         self.device = device if device is not None else default_device()
+        # matrices='corrected' (an option of the build; the default reproduces the
+        # reference): D and T^-1 built for the polynomial degree N - 1 that the N Gauss-Lobatto nodes of :398 carry
+        # (the reference uses N at :436-440 and :470-472, which differentiates no polynomial exactly), and D^2 = D @ D
+        # (the FIXME at :493).  The rest of the scheme -- boundary folding, nu-free predictor, pressure update -- is the
+        # reference's.
+        assert matrices in ['reference', 'corrected']
+        self.matrices = matrices
         self._pseudospectral_setup()
 
     # ------------------------------------------------------------------ matrix helpers (:387-531)
@@ -54,18 +61,23 @@ class NavierStokesSystem():
     def _get_T_matrix(self, N):
         return np.stack([self._get_gauss_lobatto_points(N, k=k) for k in np.arange(0, N)])
 
+    def _degree(self, N):
+        return N - 1 if self.matrices == 'corrected' else N
+
     def _get_inv_T_matrix(self, N):
+        M = self._degree(N)
         inv_T = self._get_T_matrix(N).T
-        bar_c_i = np.stack([np.repeat(self._get_bar_c_k(i, N), N) for i in np.arange(0, N)])
-        return 2 * inv_T / (bar_c_i.T * bar_c_i * N)
+        bar_c_i = np.stack([np.repeat(self._get_bar_c_k(i, M), N) for i in np.arange(0, N)])
+        return 2 * inv_T / (bar_c_i.T * bar_c_i * M)
 
     def _get_D_matrix(self, N):
         idx = np.arange(N)
         i, j = idx[:, None].astype(np.float64), idx[None, :].astype(np.float64)
-        bc = np.array([self._get_bar_c_k(k, N) for k in range(N)], dtype=np.float64)
+        M = self._degree(N)
+        bc = np.array([self._get_bar_c_k(k, M) for k in range(N)], dtype=np.float64)
         sign = np.where((idx[:, None] + idx[None, :]) % 2 == 0, 1.0, -1.0)
         with np.errstate(divide='ignore', invalid='ignore'):
-            diff = 2 * np.sin((j + i) * np.pi / (2. * N)) * np.sin((j - i) * np.pi / (2. * N))
+            diff = 2 * np.sin((j + i) * np.pi / (2. * M)) * np.sin((j - i) * np.pi / (2. * M))
             D = bc[:, None] / bc[None, :] * sign / diff
         D[idx, idx] = 0.0
         for r in range(N):
@@ -74,6 +86,8 @@ class NavierStokesSystem():
 
     def _get_D_sqr_matrix(self, N):
         D = self._get_D_matrix(N)
+        if self.matrices == 'corrected':
+            return D @ D
         D_sqr = (D @ D.T).copy()                               # FIXME in the reference (:493); kept
         for r in range(N):
             D_sqr[r, r] = -np.sum(D_sqr[r, :])                 # row sum still contains the old diagonal (:502)

@@ -30,22 +30,27 @@ def T_matrix(N):
     return np.stack([gauss_lobatto_points(N, k=k) for k in range(N)])
 
 
-def inv_T_matrix(N):
-    """:421-441"""
+def inv_T_matrix(N, corrected=False):
+    """:421-441.  corrected: the weights and the normalisation use the polynomial degree N - 1 (then inv_T @ T = I)."""
+    M = N - 1 if corrected else N
     inv_T = T_matrix(N).T
-    bc = np.array([bar_c(i, N) for i in range(N)], dtype=np.int64)
+    bc = np.array([bar_c(i, M) for i in range(N)], dtype=np.int64)
     bar_c_i = np.repeat(bc[:, None], N, axis=1)
     bar_c_k = bar_c_i.T
-    return 2 * inv_T / (bar_c_k * bar_c_i * N)
+    return 2 * inv_T / (bar_c_k * bar_c_i * M)
 
 
-def D_matrix(N):
-    """:443-481 (off-diagonals from the sin form, diagonal by the negative-sum trick)."""
+def D_matrix(N, corrected=False):
+    """:443-481 (off-diagonals from the sin form, diagonal by the negative-sum trick).
+    corrected (an option of the build): the N nodes x_j = cos(pi j / (N - 1)) of :398 carry
+    polynomials of degree N - 1, so the end-point weight is bar_c(k, N - 1) and x_i - x_j = 2 sin((i+j) pi / (2 (N-1)))
+    sin((j-i) pi / (2 (N-1))): the reference uses N in both places (:470-472), which differentiates nothing exactly."""
+    M = N - 1 if corrected else N
     i = np.arange(N)[:, None].astype(np.float64)
     j = np.arange(N)[None, :].astype(np.float64)
-    bc = np.array([bar_c(k, N) for k in range(N)], dtype=np.float64)
+    bc = np.array([bar_c(k, M) for k in range(N)], dtype=np.float64)
     with np.errstate(divide='ignore', invalid='ignore'):
-        diff = 2 * np.sin((j + i) * np.pi / (2. * N)) * np.sin((j - i) * np.pi / (2. * N))
+        diff = 2 * np.sin((j + i) * np.pi / (2. * M)) * np.sin((j - i) * np.pi / (2. * M))
         sign = np.where(((np.arange(N)[:, None] + np.arange(N)[None, :]) % 2) == 0, 1.0, -1.0)
         D = bc[:, None] / bc[None, :] * sign / diff
     D[np.arange(N), np.arange(N)] = 0.0
@@ -54,9 +59,13 @@ def D_matrix(N):
     return D
 
 
-def D_sqr_matrix(N):
+def D_sqr_matrix(N, corrected=False):
     """:483-504.  NOTE the diagonal: the row sum taken at :502 still contains the D D^T
-    diagonal entry, so d_ii = -sum_j (D D^T)_ij over ALL j (the in-code comment is wrong)."""
+    diagonal entry, so d_ii = -sum_j (D D^T)_ij over ALL j (the in-code comment is wrong).
+    corrected: the second-derivative matrix IS D @ D (the FIXME at :493)."""
+    if corrected:
+        D = D_matrix(N, corrected=True)
+        return D @ D
     D = D_matrix(N)
     D_sqr = (D @ D.T).copy()
     for r in range(N):
@@ -114,8 +123,15 @@ def boundary_constants(D, bc, ax):
 class Setup(object):
     """_pseudospectral_setup :59-199 as a plain container of arrays."""
 
-    def __init__(self, nx, ny, u_bc, v_bc):
+    def __init__(self, nx, ny, u_bc, v_bc, corrected=False):
+        """corrected=True: D, D^2 and T^-1 from the corrected constructors (the rest of the scheme is the reference's)."""
         self.nx, self.ny = nx, ny
+        if corrected:
+            self._build(nx, ny, u_bc, v_bc, lambda N: inv_T_matrix(N, True), lambda N: D_matrix(N, True), lambda N: D_sqr_matrix(N, True))
+        else:
+            self._build(nx, ny, u_bc, v_bc, inv_T_matrix, D_matrix, D_sqr_matrix)
+
+    def _build(self, nx, ny, u_bc, v_bc, inv_T_matrix, D_matrix, D_sqr_matrix):
         self.x_i, self.y_i = gauss_lobatto_points(nx), gauss_lobatto_points(ny)
         self.Tx, self.Ty = T_matrix(nx), T_matrix(ny)
         self.Tx_inv, self.Ty_inv = inv_T_matrix(nx), inv_T_matrix(ny)

@@ -76,3 +76,38 @@ def test_error_behaviour(gpu_device):
     z = np.zeros((9, 9))
     ul, vl, pl = NavierStokesSystem(z, z.copy(), z.copy(), good, good, nt=2, nx=9, ny=9).simulate()
     assert ul.shape == (2, 9, 9) and ul.dtype == np.float64
+
+
+@pytest.mark.parametrize('N', [17, 33])
+def test_corrected_matrices_option(N, gpu_device):
+    """matrices='corrected' (SURVEY section 8 (f) rank 3): the mirror's matrices equal the oracle's corrected constructors,
+    D differentiates every polynomial the nodes carry, and one predictor step on the GPU reproduces the Crank-Nicolson
+    heat step of an eigenfunction ((2 - dt lap) u* = (2 + dt lap) u, tiny amplitude so that advection is O(eps^2)) to
+    1e-8 -- which the reference's matrices miss by O(10): the default still reproduces the reference (tests above)."""
+    from src.chorin_spectral.simulate import NavierStokesSystem
+    from src.boundary import DirichletBoundaryCondition as D
+    from oracle import chorin_spectral as OS
+    h = 2. / N
+    bcs = [D(0.0, s, h, h) for s in ('left', 'right', 'top', 'bottom')]
+    dt = 1e-3
+    s = NavierStokesSystem(None, None, None, bcs, bcs, nt=1, nit=1, nx=N, ny=N, dt=dt, rho=1.0, nu=1.0, matrices='corrected')
+    assert rel_l2(s.Dx, OS.D_matrix(N, corrected=True)) < 1e-14 and rel_l2(s.Dx_sqr, OS.D_sqr_matrix(N, corrected=True)) < 1e-14
+    assert np.abs(s.Tx_inv @ s.Tx - np.eye(N)).max() < 1e-13
+    x = s.x_i
+    for k in range(1, N):
+        assert np.abs(s.Dx @ x**k - k * x**(k - 1)).max() < 1e-9 * max(1, k)**2
+    f = np.sin(np.pi * x[:, None]) * np.sin(np.pi * s.y_i[None, :])
+    eps = 1e-7
+    fac = (2 - 2 * np.pi**2 * dt) / (2 + 2 * np.pi**2 * dt)
+    ui, vi = s._predictor_step(eps * f, eps * f, eps * f, eps * f)
+    assert np.abs(ui / eps - fac * f).max() < 1e-8 and np.abs(vi / eps - fac * f).max() < 1e-8
+    ref = NavierStokesSystem(None, None, None, bcs, bcs, nt=1, nit=1, nx=N, ny=N, dt=dt, rho=1.0, nu=1.0)
+    ur, _ = ref._predictor_step(eps * f, eps * f, eps * f, eps * f)
+    assert np.abs(ur / eps - fac * f).max() > 1.0                          # the reference's matrices do not solve this problem
+    # the corrected path on the GPU == the oracle with the corrected constructors
+    S = OS.Setup(N, N, [('dirichlet', b.boundary, 0.0, h, h) for b in bcs], [('dirichlet', b.boundary, 0.0, h, h) for b in bcs], corrected=True)
+    rng = np.random.default_rng(3)
+    fields = [0.1 * rng.standard_normal((N, N)) for _ in range(4)]
+    got = s._predictor_step(*fields)
+    want = OS.predictor_step(S, *fields, dt)
+    assert rel_l2(got[0], want[0]) < 1e-8 and rel_l2(got[1], want[1]) < 1e-8

@@ -228,3 +228,26 @@ def test_corrected_adi_transposition_identity():
     a, _ = O.semi_implicit_predictor_corrected(u, v, u, v, dt, 0.1, 0.1, nu)
     b, _ = O.semi_implicit_predictor(u, v, u, v, dt, 0.1, 0.1, nu)
     assert np.abs(a - b).max() > 1e-6
+
+
+@pytest.mark.parametrize('N', [9, 17, 33])
+def test_chorin_spectral_corrected_matrices_known_answers(N):
+    """The corrected constructors (an option of the build): exact differentiation of every polynomial the N nodes carry,
+    D^2 = second derivative, T^-1 T = I -- none of which the reference's matrices satisfy (they stay the default)."""
+    x = OS.gauss_lobatto_points(N)
+    D, D2 = OS.D_matrix(N, corrected=True), OS.D_sqr_matrix(N, corrected=True)
+    for k in range(1, N):
+        assert np.abs(D @ x**k - k * x**(k - 1)).max() < 1e-10 * k * k
+    for k in range(2, N):
+        assert np.abs(D2 @ x**k - k * (k - 1) * x**(k - 2)).max() < 1e-9 * k**4
+    assert np.abs(OS.inv_T_matrix(N, corrected=True) @ OS.T_matrix(N) - np.eye(N)).max() < 1e-13
+    assert np.abs(OS.D_matrix(N) @ x - 1).max() > 0.1 and np.abs(OS.inv_T_matrix(N) @ OS.T_matrix(N) - np.eye(N)).max() > 0.5
+    # one predictor step = the Crank-Nicolson heat step of an eigenfunction (advection is O(eps^2))
+    h = 2. / N
+    bc = [('dirichlet', s, 0.0, h, h) for s in ('left', 'right', 'top', 'bottom')]
+    S = OS.Setup(N, N, bc, bc, corrected=True)
+    f = np.sin(np.pi * S.x_i[:, None]) * np.sin(np.pi * S.y_i[None, :])
+    eps, dt = 1e-7, 1e-3
+    ui, _ = OS.predictor_step(S, eps * f, eps * f, eps * f, eps * f, dt)
+    err = np.abs(ui / eps - (2 - 2 * np.pi**2 * dt) / (2 + 2 * np.pi**2 * dt) * f).max()
+    assert err < (1e-8 if N >= 17 else 1e-3)                               # spectral accuracy: N = 9 resolves sin(pi x) to ~1e-5
