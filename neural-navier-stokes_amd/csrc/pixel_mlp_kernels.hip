@@ -423,7 +423,10 @@ struct BwdLds {
     static constexpr int W_BYTES = CH * ROWB;
     static constexpr int B_BYTES = CH * 4;
     static constexpr int IMG_BYTES = 128 * ROWB;
-    __host__ __device__ static int total(int nl) { return nl * (W_BYTES + B_BYTES) + 2 * IMG_BYTES; }
+#ifndef NNS_PM_IMGSETS
+#define NNS_PM_IMGSETS 2                                       // 2: the images are double-buffered over the layers (one barrier per layer)
+#endif
+    __host__ __device__ static int total(int nl) { return nl * (W_BYTES + B_BYTES) + NNS_PM_IMGSETS * 2 * IMG_BYTES; }
 };
 
 __device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
@@ -518,8 +521,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
         __syncthreads();
     }
     const unsigned char* bias0 = lds + nl * U::W_BYTES;
-    unsigned char* imgD = lds + nl * (U::W_BYTES + U::B_BYTES);
-    unsigned char* imgA = imgD + U::IMG_BYTES;
+    unsigned char* img0 = lds + nl * (U::W_BYTES + U::B_BYTES);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
     const int bo = OT == 2 ? wave >> 1 : 0, bi = OT == 2 ? wave & 1 : 0;       // this wave's gW block
     constexpr int KS = OT == 2 ? 8 : 2;                                       // its k-steps (of 8 x 16 pixels)
@@ -593,6 +595,11 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
                     for (int s = 0; s < SS; ++s) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<ROWB>(wimg, lane, s, 32 * it), dfrag[s], nd[it], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // Consecutive layers use alternate image sets: a wave may write layer l-1's images while slower waves still read
+                // layer l's, so a layer needs ONE workgroup barrier (write -> read), not two; the set of layer l+1 is free
+                // again because every wave passed this layer's barrier after reading it.  (One more barrier per super-tile.)
+                unsigned char* imgD = img0 + (NNS_PM_IMGSETS == 2 ? (l & 1) : 0) * 2 * U::IMG_BYTES;
+                unsigned char* imgA = imgD + U::IMG_BYTES;
                 {   // delta_l and a_{l-1} as bf16 rows [32 wave + r] of the images
                     unsigned char* rowD = imgD + (32 * wave + r) * ROWB;
                     unsigned char* rowA = imgA + (32 * wave + r) * ROWB;
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
                         }
                     }
                 }
-                __syncthreads();
+                if (NNS_PM_IMGSETS != 2) __syncthreads();
                 if (l > 0) {
                     // ReLU mask a_{l-1} != 0 (activations are >= 0), then the next layer's operand fragments
 #pragma unroll
@@ -633,6 +640,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
                 }
             }
         }
+        if (NNS_PM_IMGSETS == 2) __syncthreads();          // the next super-tile's first layer may reuse the set layer 0 just read
     }
     // ---------------- partial gradients: workspace slice per workgroup (OT = 2) or per wave (OT = 1)
     float* wsb = ws + (size_t)(OT == 2 ? blockIdx.x : blockIdx.x * 4 + wave) * nparams;
