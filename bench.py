@@ -20,7 +20,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- for the dominant kernel: algorithmic bytes per launch / its average launch time,
                   measured here with HIP events on the launch stream, against the 8 TB/s HBM peak;
   cpu_baseline -- the NumPy oracle (oracle/periodic.py, kind "port") timed on this host on a bounded
-                  sample of the same workload.
+                  sample of the same workload: one core (the headline row, "cores": 1) and, as
+                  cpu_baseline.all_cores, one oracle process per usable host core (at most 16).
 """
 import argparse
 import json
@@ -89,6 +90,35 @@ def cpu_baseline(n, budget_s=20.0):
                        % (reps, n, n, el), host_cores_present=os.cpu_count())
 
 
+def _cpu_worker(arg):
+    """One host core: the same oracle loop as cpu_baseline on its own grid, for ~budget_s seconds."""
+    n, seed, budget_s = arg
+    from oracle import periodic as OP
+    from nns.synthetic import residual_inputs
+    f = [a[0].astype(np.float64) for a in residual_inputs(1, n, seed0=1234 + seed)]
+    dt, nu, rho, L = 1e-3, 2 * np.pi / 1000, 1.0, 2 * np.pi
+    h = L / n
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s:
+        OP.fd_residual(*f, dt, h, h, rho, nu, 5)
+        OP.spectral_residual(*f, dt, L, L, rho, nu)
+        reps += 1
+    return reps, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(n, budget_s=8.0, max_procs=16):
+    """The oracle on all the host cores this job may use (one process per core, one grid each: element-wise NumPy and
+    pocketfft are single-threaded).  Runs BEFORE anything touches the GPU: the workers are forked."""
+    import multiprocessing as mp
+    procs = max(1, min(max_procs, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
+    with mp.get_context('fork').Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(n, i, budget_s) for i in range(procs)])
+    rate = sum(r * n * n / t for r, t in res)
+    return dict(value=rate, unit='residual-updates/s', cores=procs,
+                sample='%d processes x (FD 5-point + rfft2 spectral residual) of one %dx%d float64 grid each, %.0f s' % (procs, n, n, budget_s))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -116,6 +146,13 @@ def main():
             raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
                              "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py ..." % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    all_cores = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('bench: timing the NumPy oracle on all host cores (before the GPU is touched) ...')
+        try:
+            all_cores = cpu_baseline_all_cores(args.n)
+        except Exception as e:                                     # noqa: BLE001 -- a reported extra, never fatal for the bench line
+            log('bench: all-core CPU baseline skipped: %r' % (e,))
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == 'nccl' else local_rank % max(ndev, 1)     # gloo rehearsal: ranks may share a GPU
     torch.cuda.set_device(dev_index)
@@ -221,6 +258,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             log('bench: timing the NumPy oracle on the host (bounded sample) ...')
             result['cpu_baseline'] = cpu_baseline(n)
+            result['cpu_baseline']['all_cores'] = all_cores        # extra row: one oracle process per usable host core
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)
