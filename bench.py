@@ -39,7 +39,9 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic (compulsory) HBM bytes per grid point, float32 fields -- derivation in DESIGN.md
-BYTES_PER_PT = {'fd_residual': 32.0, 'spec_xpass': 24.0, 'spec_ypass': 44.0}
+BYTES_PER_PT = {'fd_residual': 32.0, 'spec_xpass': 24.0, 'spec_ypass': 44.0,
+                # fused row pass (nns_residual_both_f32): u, v, p, u_prev, v_prev + 3 column-pass partials in, 3 + 3 residuals out
+                'both_rowpass': 56.0}
 
 
 def log(*a):
@@ -130,6 +132,8 @@ def main():
     ap.add_argument('--stencil', type=int, default=5)
     ap.add_argument('--fast', action='store_true', help='all-float32 spectral path (2e-4 rel-L2) instead of the precise one')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--separate', action='store_true',
+                    help='launch the FD and the spectral residual separately (3 launches) instead of the fused row pass (2 launches)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse the multi-process path on a one-GPU box)")
     ap.add_argument('--mode', choices=['batch', 'slab'], default='batch',
@@ -189,9 +193,8 @@ def main():
         out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
         out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
 
-        def step():
-            eng.fd(*f, stencil=args.stencil, out=out_fd)
-            eng.spectral(*f, out=out_sp)
+        def step():                           # FD + spectral residual of the same inputs: fused row pass when ny = 1024, 5-point
+            eng.both(*f, out_fd=out_fd, out_spec=out_sp, stencil=args.stencil, fused=not args.separate)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -223,11 +226,19 @@ def main():
     if rank == 0:
         # per-kernel durations, live, for the roofline object (same process, same inputs)
         iters = max(5, args.steps)
-        kt = {
+        fused = (not slab) and (not args.separate) and args.stencil == 5 and n == 1024
+        standalone = {
             'fd_residual': time_kernel(lambda: eng.fd(*f, stencil=args.stencil, out=out_fd), iters),
             'spec_xpass': time_kernel(lambda: ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, not args.fast, out=out_sp), iters),
             'spec_ypass': time_kernel(lambda: ops.spec_residual_ypass_(*f, *out_sp, dt, L, rho, nu, not args.fast), iters),
         }
+        if fused:                              # the launches the timed step is made of
+            ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, not args.fast, out=out_sp)
+            kt = {'spec_xpass': standalone['spec_xpass'],
+                  'both_rowpass': time_kernel(lambda: ops.residual_both(*f, dt, L, L, rho, nu, not args.fast, out_fd=out_fd, out_spec=out_sp,
+                                                                         rowpass_only=True), iters)}
+        else:
+            kt = dict(standalone)
         dom = max(kt, key=kt.get)
         alg_bytes = BYTES_PER_PT[dom] * pts
         achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
@@ -241,14 +252,17 @@ def main():
         roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=kt[dom],
                         all_kernels={k: dict(avg_launch_ms=v, bytes_per_pt=BYTES_PER_PT[k],
-                                             achieved_GBs=BYTES_PER_PT[k] * pts / (v * 1e-3) / 1e9) for k, v in kt.items()})
+                                             achieved_GBs=BYTES_PER_PT[k] * pts / (v * 1e-3) / 1e9) for k, v in kt.items()},
+                        step_launches=list(kt),
+                        standalone_kernels={k: dict(avg_launch_ms=v, bytes_per_pt=BYTES_PER_PT[k],
+                                                    achieved_GBs=BYTES_PER_PT[k] * pts / (v * 1e-3) / 1e9) for k, v in standalone.items()})
         result = dict(metric='grid-point residual-updates/sec at 1024^2 (FD 5-point + spectral residual on the same inputs)',
                       value=value, unit='residual-updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong' if slab else 'weak', vs_baseline=None,
                       dtype='f32' if args.fast else 'f32 fields; f64 forward FFT + f32 inverse FFT; f32 stencil',
                       data='synthetic',
-                      config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral'
-                                           % (n, n, B, args.stencil),
+                      config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral%s'
+                                           % (n, n, B, args.stencil, ' (fused row pass: 2 launches)' if fused else ' (separate launches)'),
                                   grid=[n, n], batch_per_gpu=B, parallelism=('row-slab x%d: RCCL halo send/recv + 2 all-to-all per spectral eval' % world) if slab else 'batch-sharded x%d (no data-path collective)' % world,
                                   inputs='Taylor-Green t=0.1 + band-limited noise, nu=2pi/1000, dt=1e-3, resident in HBM'),
                       roofline=roofline)

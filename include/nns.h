@@ -234,6 +234,22 @@ int nns_spec_residual_f32(const float* u, const float* v, const float* p, const 
                           const float* v_prev, float* r_u, float* r_v, float* r_div,
                           int batch, int nx, int ny, double dt, double Lx, double Ly,
                           double rho, double nu, int precise, void* stream);
+/* "Stencil + spectral residual on the same inputs" (the unit of BASELINE.json's metric) in two launches instead of three:
+ * the spectral column pass, then ONE row pass that completes the spectral residual AND evaluates the FD 5-point residual
+ * (the formula of nns_fd_residual_f32, float64 Laplacian): a row pass holds whole rows of u and v in registers, so the
+ * stencil's j-1 / j+1 neighbours are lane rotates and rows i-1 / i+1 come from L2 -- the inputs cross HBM once less.
+ * ny must be 1024 (one row per wave); other sizes: call the two residuals separately.  Results equal those of the two
+ * separate calls to rounding. */
+int nns_residual_both_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                          float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                          int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
+                          int precise, void* stream);
+/* Its second launch alone: sp_r_* must hold the partials of nns_spec_residual_xpass_f32 on entry (the split form, for
+ * timing the two launches separately and for callers that place an exchange between them). */
+int nns_residual_both_rowpass_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                  float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                                  int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
+                                  int precise, void* stream);
 /* The two halves of nns_spec_residual_f32, exposed for slab-decomposed (multi-GPU) use:
  * x-pass on a column slab [nx, ny_local] (needs complete columns), y-pass on a row slab
  * [nx_local, ny] (needs complete rows) which reads the x-parts from r_* and finishes them. */

@@ -89,16 +89,45 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Constants of the fused FD 5-point residual (nns_residual_both_f32): the y-pass owns whole rows, so the stencil's j-1 /
+// j+1 neighbours of u and v are already in its registers (adjacent lane, or the adjacent 64-column slot at the wave's
+// ends) and the rows i-1 / i+1 are re-read from L2 -- the stencil back-end then costs no second pass over the inputs.
+struct FdK { float inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2; };
+
+__device__ __forceinline__ float wave_ror1(float x) {          // lane i <- lane i-1, lane 0 <- lane 63
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_rol1(float x) {          // lane i <- lane i+1, lane 63 <- lane 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
+}
+// left / right neighbour (column - 1 / + 1, periodic) of slot M of a row held as element tid + 64 m in slot m (TPF = 64)
+template <int M>
+__device__ __forceinline__ float left_of(const float (&x)[16], int tid) {
+    const float l = wave_ror1(x[M]);
+    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 15) & 15]), 63));
+    return tid == 0 ? w : l;
+}
+template <int M>
+__device__ __forceinline__ float right_of(const float (&x)[16], int tid) {
+    const float r = wave_rol1(x[M]);
+    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 1) & 15]), 0));
+    return tid == 63 ? w : r;
+}
+
 // ------------------------------------------------------------------------------------------
 // y-pass: rows (contiguous lines).  One line per TPF lanes; a workgroup iteration handles
 // LINES rows; grid-stride over all batch*nx rows.
 // ------------------------------------------------------------------------------------------
-template <int N, typename TF>
+// FUSE_FD (N == 1024 only): also evaluates the FD 5-point residual of the same inputs into fu, fv, fd (fd_residual's
+// formula, float64 Laplacian) -- "stencil + spectral residual on the same inputs" in one pass over the rows.
+template <int N, typename TF, bool FUSE_FD = false>
 __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                                    const float* __restrict__ p, const float* __restrict__ up,
                                                                    const float* __restrict__ vp, float* __restrict__ ru,
                                                                    float* __restrict__ rv, float* __restrict__ rd,
-                                                                   long nrows, SpecK k) {
+                                                                   float* __restrict__ fu, float* __restrict__ fv, float* __restrict__ fd,
+                                                                   int nx, FdK fk, long nrows, SpecK k) {
+    static_assert(!FUSE_FD || N == 1024, "the fused stencil uses whole-wave rotates: one 1024-column row per wave");
     using L = SpecLds<N, TF>;
     constexpr int TPF = L::TPF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -152,6 +181,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
         deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k, hook);
         // epilogue in two halves (bounds the registers in flight next to the prefetched line): u_prev, v_prev and the
         // x-pass partials in, residuals out
+        float tu[16], tv[16];                                            // (u - u_prev)/dt, (v - v_prev)/dt: shared by both back-ends
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float pu[8], pv[8], pd[8], qu[8], qv[8];
@@ -160,16 +190,73 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                 const size_t c = base + TPF * (8 * h + i);
                 pu[i] = ru[c]; pv[i] = rv[c]; pd[i] = rd[c]; qu[i] = up[c]; qv[i] = vp[c];
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = 8 * h + i;
+                // explicitly rounded products: the fused and the plain instantiation must not differ by an FMA contraction here
+                tu[m] = __fmul_rn(uf[m] - qu[i], k.inv_dt); tv[m] = __fmul_rn(vf[m] - qv[i], k.inv_dt);
+            }
             if (valid) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int m = 8 * h + i;
                     const size_t c = base + TPF * m;
-                    ru[c] = (uf[m] - qu[i]) * k.inv_dt + pu[i] + vf[m] * a[m].x + b[m].x;
-                    rv[c] = (vf[m] - qv[i]) * k.inv_dt + pv[i] + vf[m] * a[m].y + b[m].y;
+                    // one fixed rounding sequence (the compiler may not re-associate or contract differently per instantiation)
+                    ru[c] = __fadd_rn(__fmaf_rn(vf[m], a[m].x, __fadd_rn(tu[m], pu[i])), b[m].x);
+                    rv[c] = __fadd_rn(__fmaf_rn(vf[m], a[m].y, __fadd_rn(tv[m], pv[i])), b[m].y);
                     rd[c] = pd[i] + a[m].y;
                 }
             }
+        }
+        if constexpr (FUSE_FD) {
+            // The stencil back-end, AFTER the spectral epilogue: the spectral derivatives (64 registers) are dead by now,
+            // which is what lets eight slots of eight streams be in flight per phase; the time-derivative terms are kept
+            // from the spectral epilogue.
+            __builtin_amdgcn_sched_barrier(0);
+            const long row_raw = it * L::LINES + line;
+            const long row = row_raw < nrows ? row_raw : nrows - 1;
+            const long gi = row / nx, ii = row % nx;
+            // one base pointer per stream (lane's first column included), slots at compile-time offsets TPF * m: the loads
+            // then take immediate offsets instead of eighty precomputed 64-bit addresses
+            const size_t bm = (size_t)(gi * nx + (ii == 0 ? nx - 1 : ii - 1)) * N + tidv;       // rows i-1, i+1 (periodic in the grid), i
+            const size_t bp = (size_t)(gi * nx + (ii == nx - 1 ? 0 : ii + 1)) * N + tidv;
+            const size_t bc = (size_t)row * N;
+            const float* um_p = u + bm; const float* un_p = u + bp; const float* vm_p = v + bm; const float* vn_p = v + bp;
+            const float* pm_p = p + bm; const float* pn_p = p + bp;
+            const float* pl_p = p + bc + tidv - 1;                          // column - 1: wraps only for column 0 (slot 0 of lane 0)
+            const float* pr_p = p + bc + tidv + 1;                          // column + 1: wraps only for column N-1 (slot 15 of lane 63)
+            const float* pl0_p = p + bc + ((tidv + N - 1) & (N - 1));
+            const float* pr15_p = p + bc + ((tidv + TPF * 15 + 1) & (N - 1));
+            static_for<0, 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                float um[8], un_[8], vm[8], vn_[8], pm[8], pn_[8], pl[8], pr[8];
+                static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int m = 8 * h + i;
+                    um[i] = um_p[TPF * m]; un_[i] = un_p[TPF * m]; vm[i] = vm_p[TPF * m]; vn_[i] = vn_p[TPF * m];
+                    pm[i] = pm_p[TPF * m]; pn_[i] = pn_p[TPF * m];
+                    if constexpr (m == 0) pl[i] = pl0_p[0]; else pl[i] = pl_p[TPF * m];
+                    if constexpr (m == 15) pr[i] = pr15_p[0]; else pr[i] = pr_p[TPF * m];
+                });
+                if (valid) {
+                    static_for<0, 8>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int m = 8 * h + i;
+                        const size_t c = base + TPF * m;
+                        const float ucc = uf[m], vcc = vf[m];
+                        const float ul = left_of<m>(uf, tidv), ur = right_of<m>(uf, tidv);
+                        const float vl = left_of<m>(vf, tidv), vr = right_of<m>(vf, tidv);
+                        const float ux = (un_[i] - um[i]) * fk.inv_2dx, uy = (ur - ul) * fk.inv_2dy;
+                        const float vx = (vn_[i] - vm[i]) * fk.inv_2dx, vy = (vr - vl) * fk.inv_2dy;
+                        const float px = (pn_[i] - pm[i]) * fk.inv_2dx, py = (pr[i] - pl[i]) * fk.inv_2dy;
+                        const double lu = ((double)un_[i] - 2.0 * ucc + (double)um[i]) * fk.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * fk.inv_dy2;
+                        const double lv = ((double)vn_[i] - 2.0 * vcc + (double)vm[i]) * fk.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * fk.inv_dy2;
+                        fu[c] = tu[m] + ucc * ux + vcc * uy + px * fk.inv_rho - fk.nu * (float)lu;
+                        fv[c] = tv[m] + ucc * vx + vcc * vy + py * fk.inv_rho - fk.nu * (float)lv;
+                        fd[c] = ux + vy;
+                    });
+                }
+            });
         }
     }
 }
@@ -335,11 +422,12 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
     return check_launch("spec_residual_xpass");
 }
 
-template <int N, typename TF>
+template <int N, typename TF, bool FUSE_FD = false>
 int launch_ypass(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
-                 long nrows, const SpecK& k, hipStream_t s) {
+                 long nrows, const SpecK& k, hipStream_t s, float* fu = nullptr, float* fv = nullptr, float* fd = nullptr, int nx = 1,
+                 const FdK& fk = FdK{}) {
     using L = SpecLds<N, TF>;
-    auto kern = spec_ypass_kernel<N, TF>;
+    auto kern = spec_ypass_kernel<N, TF, FUSE_FD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
@@ -349,7 +437,7 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
     const long niter = (nrows + L::LINES - 1) / L::LINES;
     const long gmax = spec_grid_cap();
     const unsigned grid = (unsigned)(niter < gmax ? niter : gmax);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, nrows, k);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, nrows, k);
     return check_launch("spec_residual_ypass");
 }
 
@@ -382,9 +470,39 @@ int ypass(const float* u, const float* v, const float* p, const float* up, const
     });
 }
 
+// FD 5-point + spectral residual of the same inputs: spectral x-pass, then the row pass with the stencil fused in.
+int residual_both(const float* u, const float* v, const float* p, const float* up, const float* vp, float* fu, float* fv, float* fd,
+                  float* ru, float* rv, float* rd, int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
+                  int precise, hipStream_t s, bool with_xpass) {
+    if (!u || !v || !p || !up || !vp || !fu || !fv || !fd || !ru || !rv || !rd || batch < 1 || nx < 3)
+        return fail(NNS_ERR_INVALID_ARG, "residual_both: bad args");
+    if (ny != 1024) return fail(NNS_ERR_UNSUPPORTED, "residual_both: the fused row pass is built for ny = 1024 (got %d): call nns_fd_residual_f32 and nns_spec_residual_f32", ny);
+    if (Ly == 0 || rho == 0 || dt == 0 || Lx == 0) return fail(NNS_ERR_INVALID_ARG, "residual_both: Lx, Ly, rho, dt must be non-zero");
+    if (with_xpass) {
+        if (int rc = xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, precise, s)) return rc;
+    }
+    const double ks = 2.0 * M_PI / Ly, dx = Lx / nx, dy = Ly / ny;
+    const SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
+    const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy)};
+    const long nrows = (long)batch * nx;
+    return precise ? launch_ypass<1024, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk)
+                   : launch_ypass<1024, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk);
+}
+
 }  // namespace
 
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+NNS_API int nns_residual_both_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                  float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                                  int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu, int precise, void* stream) {
+    return residual_both(u, v, p, u_prev, v_prev, fd_r_u, fd_r_v, fd_r_div, sp_r_u, sp_r_v, sp_r_div, batch, nx, ny, dt, Lx, Ly, rho, nu, precise, S(stream), true);
+}
+NNS_API int nns_residual_both_rowpass_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                          float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                                          int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu, int precise, void* stream) {
+    return residual_both(u, v, p, u_prev, v_prev, fd_r_u, fd_r_v, fd_r_div, sp_r_u, sp_r_v, sp_r_div, batch, nx, ny, dt, Lx, Ly, rho, nu, precise, S(stream), false);
+}
 
 NNS_API int nns_spec_residual_xpass_f32(const float* u, const float* v, const float* p, float* r_u, float* r_v, float* r_div,
                                         int batch, int nx, int ny, double Lx, double rho, double nu, int precise, void* stream) {

@@ -50,6 +50,8 @@ _DUAL = {
 }
 _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
+    'nns_residual_both_f32': [_P] * 11 + [_I] * 3 + [_D] * 5 + [_I, _P],
+    'nns_residual_both_rowpass_f32': [_P] * 11 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_bwd_f32': [_P] * 10 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_xpass_f32': [_P] * 6 + [_I] * 3 + [_D] * 3 + [_I, _P],
     'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],

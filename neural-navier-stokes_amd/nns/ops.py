@@ -250,6 +250,22 @@ def spec_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, ou
     return ru, rv, rd
 
 
+def residual_both(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, out_fd=None, out_spec=None, rowpass_only=False):
+    """FD 5-point AND spectral residual of the same inputs (the 'stencil + spectral residual' of BASELINE.json) by
+    nns_residual_both_f32: spectral column pass, then ONE row pass that also evaluates the stencil (ny = 1024).
+    Returns ((fd r_u, r_v, r_div), (spectral r_u, r_v, r_div)).  rowpass_only: out_spec already holds the column pass's
+    partials (spec_residual_xpass) and only the second launch runs."""
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
+    if suf != '_f32':
+        raise TypeError("residual_both: float32 fields")
+    fo = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
+    so = out_spec if out_spec is not None else tuple(torch.empty_like(u) for _ in range(3))
+    fn = _lib.lib().nns_residual_both_rowpass_f32 if rowpass_only else _lib.lib().nns_residual_both_f32
+    check(fn(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny,
+             dt, Lx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_residual_both_f32')
+    return fo, so
+
+
 def spec_residual_xpass(u, v, p, Lx, rho, nu, precise=True, out=None):
     suf, (B, nx, ny) = _chk(u, v, p)
     if suf != '_f32':

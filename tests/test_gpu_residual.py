@@ -327,3 +327,55 @@ def test_backward_adjoint_identity_full_size(gpu_device, backend):
     rhs = sum((a.double() * b.double()).sum().item() for a, b in zip(grads, d))
     scale = sum((a.abs() * b.double().abs()).sum().item() for a, b in zip(Jd, gr))
     assert abs(lhs - rhs) < 2e-4 * scale, (lhs, rhs, scale)
+
+
+def same_to_an_ulp(a, b):
+    """Equal except for isolated elements one or two ulps of the largest value apart."""
+    diff = (a - b).abs()
+    ulp = float(b.abs().max()) * 2.0 ** -23
+    assert float(diff.max()) <= 2 * ulp and int((diff > 0).sum()) <= max(8, a.numel() // 1000)
+
+
+@pytest.mark.parametrize('nx,batch', [(64, 3), (256, 2), (1024, 4)])
+def test_fused_both_residuals(nx, batch, gpu_device):
+    """nns_residual_both_f32 (spectral column pass + ONE row pass that also evaluates the 5-point stencil, ny = 1024):
+    the spectral outputs equal nns_spec_residual_f32 (same source, another instantiation: isolated elements may differ by
+    an ulp of the result), the stencil outputs equal nns_fd_residual_f32 to rounding and the oracle to 1e-5 -- non-square grids, several grids per batch (the i-1 / i+1 rows wrap inside each
+    grid), the split form (row pass alone), the all-float32 mode, and the engine's dispatch."""
+    from nns import ops
+    from nns.periodic import ResidualEngine
+    from oracle import periodic as OP
+    ny = 1024
+    rng = np.random.default_rng(nx)
+    x = 2 * np.pi * np.arange(nx)[:, None] / nx
+    y = 2 * np.pi * np.arange(ny)[None, :] / ny
+    f = []
+    for q in range(5):
+        a = np.stack([np.cos((1 + b) * x + q) * np.sin(2 * y - b) + 0.05 * rng.standard_normal((nx, ny)) for b in range(batch)])
+        f.append(a.astype(np.float32))
+    f[3] = (f[0] - 1e-3 * f[3]).astype(np.float32); f[4] = (f[1] - 1e-3 * f[4]).astype(np.float32)     # u_prev, v_prev close to u, v
+    d = [dev(a) for a in f]
+    Lx, Ly = 2 * np.pi * nx / ny, 2 * np.pi
+    fd_ref = ops.fd_residual(*d, DT, Lx / nx, Ly / ny, RHO, NU, 5)
+    for precise in (True, False):
+        sp_ref = ops.spec_residual(*d, DT, Lx, Ly, RHO, NU, precise)
+        fo, so = ops.residual_both(*d, DT, Lx, Ly, RHO, NU, precise)
+        for a, b in zip(so, sp_ref):
+            same_to_an_ulp(a, b)
+        for a, b in zip(fo, fd_ref):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    so2 = ops.spec_residual_xpass(d[0], d[1], d[2], Lx, RHO, NU)
+    fo2, so2 = ops.residual_both(*d, DT, Lx, Ly, RHO, NU, out_spec=so2, rowpass_only=True)
+    assert all(torch.equal(a, b) for a, b in zip(fo2, fo)) or all(rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-7 for a, b in zip(fo2, fo))
+    for a, b in zip(so2, ops.spec_residual(*d, DT, Lx, Ly, RHO, NU)):
+        same_to_an_ulp(a, b)
+    want = OP.fd_residual(*[a[0].astype(np.float64) for a in f], DT, Lx / nx, Ly / ny, RHO, NU, 5)
+    for a, b in zip(ops.residual_both(*d, DT, Lx, Ly, RHO, NU)[0], want):
+        assert rel_l2(a[0].cpu().numpy(), b) < 1e-5
+    eng = ResidualEngine(nx, ny, DT, RHO, NU, Lx, Ly)
+    (e_fd, e_sp), (s_fd, s_sp) = eng.both(*d), eng.both(*d, fused=False)
+    for a, b in zip(e_sp, s_sp):
+        same_to_an_ulp(a, b)
+    assert all(rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6 for a, b in zip(e_fd, s_fd))
+    with pytest.raises(RuntimeError):
+        ops.residual_both(*[t[:, :, :512].contiguous() for t in d], DT, Lx, Ly, RHO, NU)       # ny != 1024: loud, no silent fallback

@@ -9,7 +9,10 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(root, 'gpurun_out', 'pmc_%s_%s' % (c, tag), '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
-            s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass') if n in r['Kernel_Name']), None)
+            kn = r['Kernel_Name']
+            s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass') if n in kn), None)
+            if s == 'spec_ypass' and kn.split('(')[0].rstrip().endswith('true>'):
+                s = 'both_rowpass'                              # spec_ypass_kernel<N, TF, FUSE_FD = true>
             if s and r['Counter_Name'] == c:
                 acc[s].append(float(r['Counter_Value']))
     val[c] = {k: sum(v) / len(v) for k, v in acc.items()}
