@@ -1,7 +1,7 @@
 """Developer helper: HBM bytes per launch of the headline kernels from the two PMC passes of tools/profile_round.sh
 (gpurun_out/pmc_FETCH_SIZE_TAG, pmc_WRITE_SIZE_TAG) -> profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
 Counters are in KiB; on gfx950 FETCH_SIZE counts half of the fetched bytes (x2, /opt/skills/guides/MI355X_MICROARCH.md)."""
-import csv, glob, collections, json, os, sys
+import csv, glob, collections, json, os, re, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 val = {}
@@ -11,7 +11,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
             s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass') if n in kn), None)
-            if s == 'spec_ypass' and kn.split('(')[0].rstrip().endswith('true>'):
+            if s == 'spec_ypass' and re.search(r'spec_ypass_kernel<[^>]*true>', kn):
                 s = 'both_rowpass'                              # spec_ypass_kernel<N, TF, FUSE_FD = true>
             if s and r['Counter_Name'] == c:
                 acc[s].append(float(r['Counter_Value']))
