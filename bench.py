@@ -193,7 +193,7 @@ def main():
         out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
         out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
 
-        def step():                           # FD + spectral residual of the same inputs: fused row pass when ny = 1024, 5-point
+        def step():                           # FD + spectral residual of the same inputs: fused row pass with the 5-point stencil
             eng.both(*f, out_fd=out_fd, out_spec=out_sp, stencil=args.stencil, fused=not args.separate)
 
     def sync_all():
@@ -226,7 +226,7 @@ def main():
     if rank == 0:
         # per-kernel durations, live, for the roofline object (same process, same inputs)
         iters = max(5, args.steps)
-        fused = (not slab) and (not args.separate) and args.stencil == 5 and n == 1024
+        fused = (not slab) and (not args.separate) and args.stencil == 5
         standalone = {
             'fd_residual': time_kernel(lambda: eng.fd(*f, stencil=args.stencil, out=out_fd), iters),
             'spec_xpass': time_kernel(lambda: ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, not args.fast, out=out_sp), iters),

@@ -84,7 +84,7 @@ def cfg3():
     f = [torch.as_tensor(np.tile(a, (B // 4, 1, 1)), device='cuda') for a in residual_inputs(4, n)]
     eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000)
     o1 = tuple(torch.empty_like(f[0]) for _ in range(3)); o2 = tuple(torch.empty_like(f[0]) for _ in range(3))
-    tr = timeit(lambda: (eng.fd(*f, out=o1), eng.spectral(*f, out=o2)), iters=20)
+    tr = timeit(lambda: eng.both(*f, out_fd=o1, out_spec=o2), iters=20)            # fused: spectral column pass + row pass with the stencil
     mlp = PixelMLP(8, 64).cuda()
     x = torch.randn(16, 3, n, n, device='cuda')
     out = {}

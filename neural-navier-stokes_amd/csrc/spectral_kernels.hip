@@ -100,25 +100,40 @@ __device__ __forceinline__ float wave_ror1(float x) {          // lane i <- lane
 __device__ __forceinline__ float wave_rol1(float x) {          // lane i <- lane i+1, lane 63 <- lane 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
 }
-// left / right neighbour (column - 1 / + 1, periodic) of slot M of a row held as element tid + 64 m in slot m (TPF = 64)
-template <int M>
+// left / right neighbour (column - 1 / + 1, periodic) of slot M of a row held as element tid + TPF m in slot m by the TPF lanes
+// of one line.  TPF = 64 (one row per wave): one whole-wave DPP rotate + a readlane of the adjacent slot for the end lane.
+// TPF < 64 (several rows per wave): two ds_bpermute per neighbour (own slot from lane - 1, adjacent slot from the line's
+// last lane for tid = 0).
+template <int M, int TPF>
 __device__ __forceinline__ float left_of(const float (&x)[16], int tid) {
-    const float l = wave_ror1(x[M]);
-    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 15) & 15]), 63));
-    return tid == 0 ? w : l;
+    if constexpr (TPF == 64) {
+        const float l = wave_ror1(x[M]);
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 15) & 15]), 63));
+        return tid == 0 ? w : l;
+    } else {
+        const int lane = threadIdx.x % kWave, first = lane - tid;                 // first lane of this line
+        const float l = __shfl(x[M], lane - 1), w = __shfl(x[(M + 15) & 15], first + TPF - 1);
+        return tid == 0 ? w : l;
+    }
 }
-template <int M>
+template <int M, int TPF>
 __device__ __forceinline__ float right_of(const float (&x)[16], int tid) {
-    const float r = wave_rol1(x[M]);
-    const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 1) & 15]), 0));
-    return tid == 63 ? w : r;
+    if constexpr (TPF == 64) {
+        const float r = wave_rol1(x[M]);
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 1) & 15]), 0));
+        return tid == 63 ? w : r;
+    } else {
+        const int lane = threadIdx.x % kWave, first = lane - tid;
+        const float r = __shfl(x[M], lane + 1), w = __shfl(x[(M + 1) & 15], first);
+        return tid == TPF - 1 ? w : r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // y-pass: rows (contiguous lines).  One line per TPF lanes; a workgroup iteration handles
 // LINES rows; grid-stride over all batch*nx rows.
 // ------------------------------------------------------------------------------------------
-// FUSE_FD (N == 1024 only): also evaluates the FD 5-point residual of the same inputs into fu, fv, fd (fd_residual's
+// FUSE_FD: also evaluates the FD 5-point residual of the same inputs into fu, fv, fd (fd_residual's
 // formula, float64 Laplacian) -- "stencil + spectral residual on the same inputs" in one pass over the rows.
 template <int N, typename TF, bool FUSE_FD = false>
 __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* __restrict__ u, const float* __restrict__ v,
@@ -127,7 +142,6 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                                                                    float* __restrict__ rv, float* __restrict__ rd,
                                                                    float* __restrict__ fu, float* __restrict__ fv, float* __restrict__ fd,
                                                                    int nx, FdK fk, long nrows, SpecK k) {
-    static_assert(!FUSE_FD || N == 1024, "the fused stencil uses whole-wave rotates: one 1024-column row per wave");
     using L = SpecLds<N, TF>;
     constexpr int TPF = L::TPF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -244,8 +258,8 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                         constexpr int m = 8 * h + i;
                         const size_t c = base + TPF * m;
                         const float ucc = uf[m], vcc = vf[m];
-                        const float ul = left_of<m>(uf, tidv), ur = right_of<m>(uf, tidv);
-                        const float vl = left_of<m>(vf, tidv), vr = right_of<m>(vf, tidv);
+                        const float ul = left_of<m, TPF>(uf, tidv), ur = right_of<m, TPF>(uf, tidv);
+                        const float vl = left_of<m, TPF>(vf, tidv), vr = right_of<m, TPF>(vf, tidv);
                         const float ux = (un_[i] - um[i]) * fk.inv_2dx, uy = (ur - ul) * fk.inv_2dy;
                         const float vx = (vn_[i] - vm[i]) * fk.inv_2dx, vy = (vr - vl) * fk.inv_2dy;
                         const float px = (pn_[i] - pm[i]) * fk.inv_2dx, py = (pr[i] - pl[i]) * fk.inv_2dy;
@@ -476,7 +490,7 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
                   int precise, hipStream_t s, bool with_xpass) {
     if (!u || !v || !p || !up || !vp || !fu || !fv || !fd || !ru || !rv || !rd || batch < 1 || nx < 3)
         return fail(NNS_ERR_INVALID_ARG, "residual_both: bad args");
-    if (ny != 1024) return fail(NNS_ERR_UNSUPPORTED, "residual_both: the fused row pass is built for ny = 1024 (got %d): call nns_fd_residual_f32 and nns_spec_residual_f32", ny);
+    if (!pow2_in_range(ny) || !pow2_in_range(nx)) return fail(NNS_ERR_UNSUPPORTED, "residual_both: nx=%d, ny=%d must be powers of two in [64, 1024]", nx, ny);
     if (Ly == 0 || rho == 0 || dt == 0 || Lx == 0) return fail(NNS_ERR_INVALID_ARG, "residual_both: Lx, Ly, rho, dt must be non-zero");
     if (with_xpass) {
         if (int rc = xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, precise, s)) return rc;
@@ -485,8 +499,11 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     const SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy)};
     const long nrows = (long)batch * nx;
-    return precise ? launch_ypass<1024, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk)
-                   : launch_ypass<1024, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk);
+    return dispatch_n(ny, [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        return precise ? launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk)
+                       : launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk);
+    });
 }
 
 }  // namespace

@@ -252,7 +252,7 @@ def spec_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, ou
 
 def residual_both(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, out_fd=None, out_spec=None, rowpass_only=False):
     """FD 5-point AND spectral residual of the same inputs (the 'stencil + spectral residual' of BASELINE.json) by
-    nns_residual_both_f32: spectral column pass, then ONE row pass that also evaluates the stencil (ny = 1024).
+    nns_residual_both_f32: spectral column pass, then ONE row pass that also evaluates the stencil.
     Returns ((fd r_u, r_v, r_div), (spectral r_u, r_v, r_div)).  rowpass_only: out_spec already holds the column pass's
     partials (spec_residual_xpass) and only the second launch runs."""
     suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)

@@ -52,11 +52,11 @@ class ResidualEngine(object):
         return (r_u * r_u).mean() + (r_v * r_v).mean() + w_div * (r_d * r_d).mean()
 
     def both(self, u, v, p, u_prev, v_prev, out_fd=None, out_spec=None, stencil=5, fused=True):
-        """The 'stencil + spectral residual' of BASELINE.json: both back-ends on the same inputs.  With the 5-point stencil,
-        float32 fields and ny = 1024 this is nns_residual_both_f32: the spectral column pass and ONE row pass that also
+        """The 'stencil + spectral residual' of BASELINE.json: both back-ends on the same inputs.  With the 5-point stencil
+        and float32 fields this is nns_residual_both_f32: the spectral column pass and ONE row pass that also
         evaluates the stencil (the inputs cross HBM once less); otherwise, or with fused=False, the two back-ends are
         launched separately.  Same results either way, to rounding."""
-        if fused and stencil == 5 and self.ny == 1024 and u.dtype == torch.float32:
+        if fused and stencil == 5 and u.dtype == torch.float32:
             return ops.residual_both(u, v, p, u_prev, v_prev, self.dt, self.Lx, self.Ly, self.rho, self.nu, self.precise,
                                      out_fd=out_fd, out_spec=out_spec)
         return (self.fd(u, v, p, u_prev, v_prev, stencil, out_fd), self.spectral(u, v, p, u_prev, v_prev, out_spec))
