@@ -115,7 +115,7 @@ def cpu_baseline_all_cores(n, budget_s=8.0, max_procs=16):
     import multiprocessing as mp
     procs = max(1, min(max_procs, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
     with mp.get_context('fork').Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(n, i, budget_s) for i in range(procs)])
+        res = pool.map_async(_cpu_worker, [(n, i, budget_s) for i in range(procs)]).get(timeout=6 * budget_s + 30)   # never hang the bench line
     rate = sum(r * n * n / t for r, t in res)
     return dict(value=rate, unit='residual-updates/s', cores=procs,
                 sample='%d processes x (FD 5-point + rfft2 spectral residual) of one %dx%d float64 grid each, %.0f s' % (procs, n, n, budget_s))
