@@ -108,6 +108,9 @@ def cfg3():
         e2 = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
         ts = timeit(lambda: train_step(stepper, e2, opt, state, target, lam=0.1), iters=10)
         out['physics_informed_step_d8_w64_bf16_%s' % backend] = dict(ms=1e3 * ts, Mpix_s=16 * n * n / ts / 1e6)
+        s_cm, t_cm = state.transpose(0, 1).contiguous(), target.transpose(0, 1).contiguous()     # channel-major fields: no per-channel copies
+        tc = timeit(lambda: train_step(stepper, e2, opt, s_cm, t_cm, lam=0.1, layout='cm'), iters=10)
+        out['physics_informed_step_d8_w64_bf16_%s_channel_major' % backend] = dict(ms=1e3 * tc, Mpix_s=16 * n * n / tc / 1e6)
     return dict(config='cfg3 512x512 Re=1000: residual (FD5 + spectral, batch 64) + depth-8 width-64 pixel MLP',
                 residual_updates_per_s=B * n * n / tr, **out)
 

@@ -25,24 +25,38 @@ class FieldStepper(torch.nn.Module):
     def forward(self, state):
         return state + self.mlp.train_forward(state)
 
+    def forward_cm(self, state_cm):
+        """Channel-major fields [3, B, nx, ny]: the per-pixel MLP sees them as ONE batch item of B nx ny pixels, so the
+        prediction's channels come out as three contiguous [B, nx, ny] fields -- no per-channel copies around the residual."""
+        c, B, nx, ny = state_cm.shape
+        out = self.mlp.train_forward(state_cm.reshape(1, c, B * nx * ny))
+        return state_cm + out.reshape(c, B, nx, ny)
 
-def physics_informed_loss(model, engine, state, target=None, lam=1.0, w_div=1.0):
-    """state, target: [B, 3, nx, ny] float32 (channels u, v, p).  Returns (total, data, physics)."""
-    pred = model(state)
-    u, v, p = (pred[:, c].contiguous() for c in range(3))
-    phys = engine.physics_loss(u, v, p, state[:, 0].contiguous(), state[:, 1].contiguous(), w_div=w_div)
+
+def physics_informed_loss(model, engine, state, target=None, lam=1.0, w_div=1.0, layout='bchw'):
+    """state, target: float32 fields (channels u, v, p), [B, 3, nx, ny] (layout='bchw') or channel-major [3, B, nx, ny]
+    (layout='cm': the residual kernels take the prediction's channels in place, and their gradients return by one
+    stack instead of three strided scatters).  Returns (total, data, physics)."""
+    if layout == 'cm':
+        pred = model.forward_cm(state)
+        u, v, p = torch.unbind(pred, 0)                                   # contiguous views; backward = one stack
+        phys = engine.physics_loss(u, v, p, state[0], state[1], w_div=w_div)
+    else:
+        pred = model(state)
+        u, v, p = (pred[:, c].contiguous() for c in range(3))
+        phys = engine.physics_loss(u, v, p, state[:, 0].contiguous(), state[:, 1].contiguous(), w_div=w_div)
     data = ((pred - target) ** 2).mean() if target is not None else torch.zeros((), device=pred.device)
     return data + lam * phys, data, phys
 
 
-def train_step(model, engine, optimizer, state, target=None, lam=1.0, w_div=1.0, bucket=None):
+def train_step(model, engine, optimizer, state, target=None, lam=1.0, w_div=1.0, bucket=None, layout='bchw'):
     """One optimiser step.  Data-parallel runs pass `bucket` (nns.data_parallel.FlatGradAllReduce over the model's
     parameters): each rank works on its shard of the batch and the gradients are averaged with ONE all-reduce."""
     if bucket is not None:
         bucket.zero_()
     else:
         optimizer.zero_grad(set_to_none=True)
-    total, data, phys = physics_informed_loss(model, engine, state, target, lam, w_div)
+    total, data, phys = physics_informed_loss(model, engine, state, target, lam, w_div, layout=layout)
     total.backward()
     if bucket is not None:
         bucket.reduce_()

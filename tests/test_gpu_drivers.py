@@ -89,6 +89,14 @@ def test_physics_informed_training_step(gpu_device):
     for got, q in zip(saved, model.parameters()):
         num = (got - q.grad).norm().item(); den = q.grad.norm().item()
         assert num < 6e-2 * den + 1e-6, (num, den)
+    # channel-major layout: the same loss and the same gradients (same kernels, other pixel order)
+    for q in model.parameters():
+        q.grad = None
+    t_cm, d_cm, p_cm = physics_informed_loss(model, eng, state.transpose(0, 1).contiguous(), target.transpose(0, 1).contiguous(), lam=0.1, layout='cm')
+    t_cm.backward()
+    assert abs(t_cm.item() - total.item()) < 1e-5 * abs(total.item())
+    for got, q in zip(saved, model.parameters()):
+        assert (got - q.grad).norm().item() < 2e-3 * got.norm().item() + 1e-7
     # and it trains
     opt = torch.optim.Adam(model.parameters(), lr=2e-3)
     hist = [train_step(model, eng, opt, state, target, lam=0.1)[0].item() for _ in range(40)]
