@@ -156,6 +156,14 @@ int nns_fd_sor_redblack_halfsweep_f32(float* p, const float* C, void* err_bits, 
                                       double dx, double dy, double beta, void* stream);
 int nns_fd_sor_redblack_halfsweep_f64(double* p, const double* C, void* err_bits, int nxl, int ny, int gi0, int colour,
                                       double dx, double dy, double beta, void* stream);
+/* The same half-sweep as one link of a pre-enqueued chain: it runs only if *prev_err_bits (the previous sweep's error, same
+ * bit-pattern format, already max-reduced over the ranks by the caller) is > tol -- the reference's `while err > tol`
+ * (src/chorin_fd/simulate.py:190) evaluated on the device; a skipped colour-1 half-sweep stores the all-ones-but-sign (NaN)
+ * pattern in *err_bits so that everything after it stays off.  No host round trip per sweep. */
+int nns_fd_sor_redblack_halfsweep_gated_f32(float* p, const float* C, void* err_bits, const void* prev_err_bits, double tol,
+                                            int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, void* stream);
+int nns_fd_sor_redblack_halfsweep_gated_f64(double* p, const double* C, void* err_bits, const void* prev_err_bits, double tol,
+                                            int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, void* stream);
 
 /* spatial_coarsen (src/utils.py:13-60): block means over agg_x x agg_y cells of the [nt][nx][ny] sequences u, v, p into
  * [nt][nx/agg_x][ny/agg_y], one launch for the three fields.  The add order of numpy.mean (pairwise) is reproduced, so
@@ -205,6 +213,18 @@ int nns_fd_residual_f64(const double* u, const double* v, const double* p, const
                         const double* v_prev, double* r_u, double* r_v, double* r_div,
                         int batch, int nx, int ny, double dt, double dx, double dy,
                         double rho, double nu, int stencil, void* stream);
+/* The FD residual on local rows [row_begin, row_end) of a ROW SLAB [batch][nx_local][ny] (grids sharded by rows over ranks,
+ * nns/slab.py): rows -1 and nx_local come from halo_top / halo_bot ([3 (u, v, p)][batch][ny] messages from the ring
+ * neighbours).  Interior rows [1, nx_local-1) never touch the halos, so they can be launched while the exchange is in
+ * flight and the two edge rows afterwards ("overlap interior compute with halo"). */
+int nns_fd_residual_halo_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                             const float* halo_top, const float* halo_bot, float* r_u, float* r_v, float* r_div,
+                             int batch, int nx_local, int ny, int row_begin, int row_end, double dt, double dx, double dy,
+                             double rho, double nu, int stencil, void* stream);
+int nns_fd_residual_halo_f64(const double* u, const double* v, const double* p, const double* u_prev, const double* v_prev,
+                             const double* halo_top, const double* halo_bot, double* r_u, double* r_v, double* r_div,
+                             int batch, int nx_local, int ny, int row_begin, int row_end, double dt, double dx, double dy,
+                             double rho, double nu, int stencil, void* stream);
 /* Vector-Jacobian product of the FD residual (the physics-informed loss' backward;
  * oracle/periodic.py: fd_residual_vjp).  g_* = dLoss/dr_*; outputs dLoss/du, /dv, /dp and, when the pointers are
  * non-null, dLoss/du_prev = -g_u/dt, dLoss/dv_prev = -g_v/dt.  Adjoint stencils (D^T = -D, L^T = L); p does not enter. */
@@ -253,12 +273,29 @@ int nns_residual_both_rowpass_f32(const float* u, const float* v, const float* p
                                   float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
                                   int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
                                   int precise, void* stream);
+/* The row pass on a ROW SLAB [batch][nx_local][ny] of grids sharded by rows over ranks (nns/slab.py):
+ * the stencil's row above local row 0 / below local row nx_local-1 is read from halo_top / halo_bot, two
+ * [3 (u, v, p)][batch][ny] messages holding the neighbour ranks' edge rows; dx is the grid spacing along x (the slab does not
+ * know the global row count); nx_local >= 3, any value.  Same arithmetic per point as nns_residual_both_rowpass_f32. */
+int nns_residual_both_rowpass_halo_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                       const float* halo_top, const float* halo_bot,
+                                       float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                                       int batch, int nx_local, int ny, double dt, double dx, double Ly, double rho, double nu,
+                                       int precise, void* stream);
 /* The two halves of nns_spec_residual_f32, exposed for slab-decomposed (multi-GPU) use:
  * x-pass on a column slab [nx, ny_local] (needs complete columns), y-pass on a row slab
  * [nx_local, ny] (needs complete rows) which reads the x-parts from r_* and finishes them. */
 int nns_spec_residual_xpass_f32(const float* u, const float* v, const float* p,
                                 float* r_u, float* r_v, float* r_div, int batch, int nx, int ny,
                                 double Lx, double rho, double nu, int precise, void* stream);
+/* The column pass on a COLUMN SLAB whose rows arrive from an all-to-all in blocks of seg_rows rows per source rank:
+ * u, v, p (and the partials written to r_*) are laid out [src][...][batch][seg_rows][ny] -- row r of grid b of a field
+ * starts at field + (r / seg_rows) * seg_stride + b * seg_rows * ny + (r % seg_rows) * ny.  seg_rows: a power of two <= nx.
+ * Reading the receive buffer and writing the send buffer of the return all-to-all in place removes the permuting copies on
+ * both sides of the column pass.  Same arithmetic per column as nns_spec_residual_xpass_f32. */
+int nns_spec_residual_xpass_seg_f32(const float* u, const float* v, const float* p, float* r_u, float* r_v, float* r_div,
+                                    int batch, int nx, int ny, int seg_rows, long seg_stride, double Lx, double rho, double nu,
+                                    int precise, void* stream);
 int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, const float* u_prev,
                                 const float* v_prev, float* r_u, float* r_v, float* r_div,
                                 int batch, int nx, int ny, double dt, double Ly,
@@ -303,6 +340,12 @@ int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const float* 
 /* Its gradients for g = scale * (pred - obs): gcoeff [T, K, C] (zeroed inside, atomics) and gbasis [K, C, P]. */
 int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* obs, float scale,
                            float* gcoeff, float* gbasis, int T, int K, int C, int P, void* stream);
+/* Loss and gradient in ONE sweep over the observations (training step, spectral_ode.py:178-190: forward, loss.backward()):
+ * *sumsq += sum (pred - obs)^2 (zeroed by the caller) and gcoeff / gbasis = d(sumsq / 2) / d(coeff, basis), i.e. the gradient
+ * WITHOUT the upstream / loss factor, which the caller applies afterwards (the gradient is linear in it).  obs, the only
+ * large stream, is read once instead of twice. */
+int nns_basis_loss_fused_f32(const float* coeff, const float* basis, const float* obs, double* sumsq, float* gcoeff, float* gbasis,
+                             int T, int K, int C, int P, void* stream);
 
 /* Per-pixel MLP forward (BasisFunc, spectral_ode.py:100-119: a stack of 1x1 Conv2d with ReLU between layers,
  * generalised to <= 8 layers of width <= 64): x [mb, widths[0], P] -> y [mb, widths[nlayers], P], P = nx*ny.
@@ -340,6 +383,27 @@ int nns_cheb_diag_div_f64(const double* Hm, const double* lam_x, const double* l
  * (:322-334). */
 int nns_cheb_embed_f64(const double* sol, const double* x0, const double* xN, const double* y0, const double* yN,
                        double* full, int Nx, int Ny, void* stream);
+
+/* ---- slab decomposition of one grid over the GPUs of a node: device-side message packing (nns/slab.py) --------------
+ * No reference counterpart (src/neural_spectral/spectral_ode.py:155-156 runs on one device); SURVEY.md section 8 (e).
+ * fields_host: a HOST array of nfields (<= 4) device pointers.  One launch each.
+ * gather:  msg[f][o][e] = fields[f][o * outer_stride + line_off + e * elem_stride],  o < nouter, e < len;  scatter: the reverse.
+ *   (a row of [B][nloc][ny] slabs: nouter = B, outer_stride = nloc * ny, line_off = row * ny, len = ny, elem_stride = 1;
+ *    a column of an [nx][nyl] slab: nouter = 1, line_off = column, len = nx, elem_stride = nyl) */
+int nns_slab_gather_lines_f32(const float* const* fields_host, int nfields, float* msg, long nouter, long outer_stride, long line_off,
+                              long len, long elem_stride, void* stream);
+int nns_slab_gather_lines_f64(const double* const* fields_host, int nfields, double* msg, long nouter, long outer_stride, long line_off,
+                              long len, long elem_stride, void* stream);
+int nns_slab_scatter_lines_f32(const float* msg, float* const* fields_host, int nfields, long nouter, long outer_stride, long line_off,
+                               long len, long elem_stride, void* stream);
+int nns_slab_scatter_lines_f64(const double* msg, double* const* fields_host, int nfields, long nouter, long outer_stride, long line_off,
+                               long len, long elem_stride, void* stream);
+/* transpose_pack: row slabs fields[f][b][i][j] -> send[d][f][b][i][jj], d = j / (ny / nranks): the all-to-all send buffer with every
+ * destination's column block contiguous; transpose_unpack: recv[s][f][b][i][jj] -> fields[f][b][i][s * (ny / nranks) + jj]. */
+int nns_slab_transpose_pack_f32(const float* const* fields_host, int nfields, float* send, int batch, int nloc, int ny, int nranks, void* stream);
+int nns_slab_transpose_pack_f64(const double* const* fields_host, int nfields, double* send, int batch, int nloc, int ny, int nranks, void* stream);
+int nns_slab_transpose_unpack_f32(const float* recv, float* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream);
+int nns_slab_transpose_unpack_f64(const double* recv, double* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -453,8 +453,8 @@ __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict
                         for (int k = 0; k < KMAX; ++k) pred = fmaf(w[k], fk[i][k], pred);
                     }
                     const float r = (ok[i] && row_ok) ? (MODE == 2 ? ob[i] : pred - ob[i]) : 0.f;
-                    if (MODE == 0) local += (double)r * (double)r;
-                    g[i] = MODE == 2 ? r : scale * r;
+                    if (MODE == 0 || MODE == 3) local += (double)r * (double)r;
+                    g[i] = (MODE == 2 || MODE == 3) ? r : scale * r;
                 }
                 if (MODE != 0) {
 #pragma unroll
@@ -469,10 +469,11 @@ __global__ __launch_bounds__(256) void basis_loss_kernel(const float* __restrict
             if (MODE != 0) flush_part(t0 + tt0);
         }
     }
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 3) {
         for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_down(local, o);
         if (lane == 0) atomicAdd(sumsq, local);
-    } else {
+    }
+    if (MODE != 0) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             if (ok[i]) {
@@ -580,6 +581,7 @@ __global__ __launch_bounds__(256) NNS_PK_ATTR void basis_loss_pk_kernel(const fl
     // rows per (prefetch) group and per butterfly.  (Prefetching two butterflies ahead in the gradient modes -- TT = TT0 --
     // measured the same 3.0 ms at 254 registers instead of 190.)
     constexpr int RB = PkGeom<KMAX>::TT1, TT = MODE == 0 ? PkGeom<KMAX>::TT0 : RB;
+    constexpr bool WANT_SS = MODE == 0 || MODE == 3;                   // MODE 3 = loss AND unscaled gradients in ONE sweep over the observations
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* cw = reinterpret_cast<float*>(smem_raw);                    // [TC][KMAX], zero-padded (no k < K guard in the hot loop)
     const int c = blockIdx.y, tid = threadIdx.x, lane = tid % kWave;
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(256) NNS_PK_ATTR void basis_loss_pk_kernel(const fl
 #pragma unroll
                     for (int i = 0; i < NP; ++i) g[i] = ob[i];
                 }
-                if constexpr (MODE == 0) {
+                if constexpr (WANT_SS) {
                     const float rowm = tt < tn ? 1.f : 0.f;
 #pragma unroll
                     for (int i = 0; i < NP; ++i) { const float r = g[i] * (okm[i] * rowm); local += (double)r * (double)r; }
@@ -709,10 +711,11 @@ __global__ __launch_bounds__(256) NNS_PK_ATTR void basis_loss_pk_kernel(const fl
             });
         }
     }
-    if constexpr (MODE == 0) {
+    if constexpr (WANT_SS) {
         for (int o = kWave / 2; o > 0; o >>= 1) local += __shfl_down(local, o);
         if (lane == 0) atomicAdd(sumsq, local);
-    } else {
+    }
+    if constexpr (MODE != 0) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int px = pbase + 256 * i;
@@ -857,6 +860,22 @@ NNS_API int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_bwd: memset: %s", hipGetErrorString(e));
     launch_loss<1>(g, S(stream), coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P);
     return check_launch("basis_loss_bwd");
+}
+
+// ONE sweep over the observations for the loss AND its gradient: *sumsq += sum (pred - obs)^2 (the caller zeroes it),
+// gcoeff / gbasis = the gradient of sumsq / 2, i.e. UNSCALED by the upstream factor; d ||.||_2 = (upstream / loss) * these
+// (the gradient is linear in that scalar, so the caller applies it afterwards -- obs is read once instead of twice).
+NNS_API int nns_basis_loss_fused_f32(const float* coeff, const float* basis, const float* obs, double* sumsq, float* gcoeff, float* gbasis,
+                                     int T, int K, int C, int P, void* stream) {
+    if (!coeff || !basis || !obs || !sumsq || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_fused: bad args");
+    if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: K=%d > %d", K, kMaxK);
+    if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: C must be <= 65535");
+    const LossGeom g = loss_geom(T, K, C, P);
+    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
+    if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_fused: memset: %s", hipGetErrorString(e));
+    launch_loss<3>(g, S(stream), coeff, basis, obs, sumsq, gcoeff, gbasis, 1.f, T, K, C, P);
+    return check_launch("basis_loss_fused");
 }
 
 // Backward of nns_basis_expand_f32 for an arbitrary upstream gradient grad_pred [T, C, P].

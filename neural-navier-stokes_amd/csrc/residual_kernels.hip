@@ -45,6 +45,18 @@ inline ResK<T> make_resk(double dt, double dx, double dy, double rho, double nu)
 template <typename T, int V>
 struct Row { T v[V]; T l, r; };          // V consecutive columns of one row + the two neighbours
 
+// Row slabs of a grid sharded over ranks (nns/slab.py): rows -1 and nx of the local slab are the neighbour ranks' edge rows,
+// delivered as [u, v, p][grid][ny] messages (fstride = grids * ny).  NULL = the rows wrap around inside the local grid.
+// [r0, r1) = the local rows this launch evaluates (interior rows first, the two edge rows once the halos have arrived).
+template <typename T>
+struct HaloRows { const T* top; const T* bot; long fstride; int r0, r1; };
+template <typename T>
+__device__ __forceinline__ const T* halo_row(const T* grid_base, const HaloRows<T>& hr, int field, int b, int i, int nx, int ny) {
+    if (i < 0) return hr.top ? hr.top + field * hr.fstride + (size_t)b * ny : grid_base + (size_t)(nx - 1) * ny;
+    if (i >= nx) return hr.bot ? hr.bot + field * hr.fstride + (size_t)b * ny : grid_base;
+    return grid_base + (size_t)i * ny;
+}
+
 #ifndef NNS_FD_NT
 #define NNS_FD_NT 0        // 1: non-temporal hint on the write-once outputs and read-once u_prev / v_prev streams
 #endif
@@ -99,7 +111,7 @@ template <typename T, int STENCIL>
 __global__ __launch_bounds__(256) void fd_residual_vec_kernel(const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ p,
                                                                const T* __restrict__ up, const T* __restrict__ vp,
                                                                T* __restrict__ ru, T* __restrict__ rv, T* __restrict__ rd,
-                                                               int nx, int ny, int R, int nbands, int nstrips, ResK<T> k) {
+                                                               int nx, int ny, int R, int nbands, int nstrips, ResK<T> k, HaloRows<T> hr) {
     constexpr int V = VecT<T>::V;
     const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     const int strip = lb % nstrips, band = (lb / nstrips) % nbands, b = lb / (nstrips * nbands);
@@ -115,21 +127,21 @@ __global__ __launch_bounds__(256) void fd_residual_vec_kernel(const T* __restric
     const bool need_r = lane == kWave - 1 || jv_raw >= nvec - 1;
     const size_t g = (size_t)b * nx * ny;
     const T* ug = u + g; const T* vg = v + g; const T* pg = p + g;
-    const int i0 = band * R, i1 = min(nx, i0 + R);
-    if (i0 >= nx) return;
+    const int i0 = hr.r0 + band * R, i1 = min(hr.r1, i0 + R);
+    if (i0 >= hr.r1) return;
 
     Row<T, V> um, uc, un, vm, vc, vn, pm, pc, pn;
     {
-        const size_t rm = (size_t)(i0 == 0 ? nx - 1 : i0 - 1) * ny, rc = (size_t)i0 * ny;
-        load_row<T>(ug + rm, j0, jl, jr, need_l, need_r, um); load_row<T>(ug + rc, j0, jl, jr, need_l, need_r, uc);
-        load_row<T>(vg + rm, j0, jl, jr, need_l, need_r, vm); load_row<T>(vg + rc, j0, jl, jr, need_l, need_r, vc);
-        load_row<T>(pg + rm, j0, jl, jr, need_l, need_r, pm); load_row<T>(pg + rc, j0, jl, jr, need_l, need_r, pc);
+        const size_t rc = (size_t)i0 * ny;
+        load_row<T>(halo_row<T>(ug, hr, 0, b, i0 - 1, nx, ny), j0, jl, jr, need_l, need_r, um); load_row<T>(ug + rc, j0, jl, jr, need_l, need_r, uc);
+        load_row<T>(halo_row<T>(vg, hr, 1, b, i0 - 1, nx, ny), j0, jl, jr, need_l, need_r, vm); load_row<T>(vg + rc, j0, jl, jr, need_l, need_r, vc);
+        load_row<T>(halo_row<T>(pg, hr, 2, b, i0 - 1, nx, ny), j0, jl, jr, need_l, need_r, pm); load_row<T>(pg + rc, j0, jl, jr, need_l, need_r, pc);
     }
     for (int i = i0; i < i1; ++i) {
-        const size_t rn = (size_t)(i + 1 == nx ? 0 : i + 1) * ny, rc = g + (size_t)i * ny + j0;
-        load_row<T>(ug + rn, j0, jl, jr, need_l, need_r, un);
-        load_row<T>(vg + rn, j0, jl, jr, need_l, need_r, vn);
-        load_row<T>(pg + rn, j0, jl, jr, need_l, need_r, pn);
+        const size_t rc = g + (size_t)i * ny + j0;
+        load_row<T>(halo_row<T>(ug, hr, 0, b, i + 1, nx, ny), j0, jl, jr, need_l, need_r, un);
+        load_row<T>(halo_row<T>(vg, hr, 1, b, i + 1, nx, ny), j0, jl, jr, need_l, need_r, vn);
+        load_row<T>(halo_row<T>(pg, hr, 2, b, i + 1, nx, ny), j0, jl, jr, need_l, need_r, pn);
         T upv[V], vpv[V], o_u[V], o_v[V], o_d[V];
         load_vec<T>(up + rc, upv, true);
         load_vec<T>(vp + rc, vpv, true);
@@ -166,13 +178,13 @@ template <typename T, int STENCIL>
 __global__ __launch_bounds__(256) void fd_residual_generic_kernel(const T* __restrict__ u, const T* __restrict__ v, const T* __restrict__ p,
                                                                    const T* __restrict__ up, const T* __restrict__ vp,
                                                                    T* __restrict__ ru, T* __restrict__ rv, T* __restrict__ rd,
-                                                                   int nx, int ny, ResK<T> k) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+                                                                   int nx, int ny, ResK<T> k, HaloRows<T> hr) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = hr.r0 + blockIdx.y;
     if (j >= ny) return;
     const size_t g = (size_t)blockIdx.z * nx * ny;
-    const int im = i == 0 ? nx - 1 : i - 1, in = i + 1 == nx ? 0 : i + 1;
+    const int im = i - 1, in = i + 1;                       // -1 / nx: the halo rows (or the periodic wrap), see halo_row
     const int jm = j == 0 ? ny - 1 : j - 1, jn = j + 1 == ny ? 0 : j + 1;
-    auto at = [&](const T* f, int a, int b) { return f[g + (size_t)a * ny + b]; };
+    auto at = [&](const T* f, int a, int b) { return halo_row<T>(f + g, hr, f == u ? 0 : f == v ? 1 : 2, (int)blockIdx.z, a, nx, ny)[b]; };
     const T ucc = at(u, i, j), vcc = at(v, i, j);
     const T ue = at(u, in, j), uw = at(u, im, j), ur = at(u, i, jn), ul = at(u, i, jm);
     const T ve = at(v, in, j), vw = at(v, im, j), vr = at(v, i, jn), vl = at(v, i, jm);
@@ -193,9 +205,16 @@ __global__ __launch_bounds__(256) void fd_residual_generic_kernel(const T* __res
 
 template <typename T>
 int fd_residual(const T* u, const T* v, const T* p, const T* up, const T* vp, T* ru, T* rv, T* rd, int batch, int nx, int ny,
-                double dt, double dx, double dy, double rho, double nu, int stencil, hipStream_t s) {
+                double dt, double dx, double dy, double rho, double nu, int stencil, hipStream_t s,
+                const T* halo_top = nullptr, const T* halo_bot = nullptr, int r0 = 0, int r1 = -1) {
     if (!u || !v || !p || !up || !vp || !ru || !rv || !rd || !field_args_ok(batch, nx, ny))
         return fail(NNS_ERR_INVALID_ARG, "fd_residual: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
+    if (r1 < 0) r1 = nx;
+    if (r0 < 0 || r1 > nx || r0 > r1) return fail(NNS_ERR_INVALID_ARG, "fd_residual: row range [%d, %d) not inside [0, %d)", r0, r1, nx);
+    if ((halo_top == nullptr) != (halo_bot == nullptr)) return fail(NNS_ERR_INVALID_ARG, "fd_residual: halo_top and halo_bot go together");
+    if (r0 == r1) return NNS_OK;
+    const HaloRows<T> hr{halo_top, halo_bot, (long)batch * ny, r0, r1};
+    const int nr = r1 - r0;
     if (stencil != 5 && stencil != 9) return fail(NNS_ERR_INVALID_ARG, "fd_residual: stencil must be 5 or 9 (got %d)", stencil);
     if (dt == 0 || dx == 0 || dy == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "fd_residual: dt, dx, dy, rho must be non-zero");
     const ResK<T> k = make_resk<T>(dt, dx, dy, rho, nu);
@@ -207,21 +226,22 @@ int fd_residual(const T* u, const T* v, const T* p, const T* up, const T* vp, T*
         const int nvec = ny / V, nstrips = (nvec + 255) / 256;
         // rows per band: aim for >= 2048 workgroups, keep the halo overhead (R+2)/R small
         long want = 2048;
-        int R = (int)(((long)batch * nx * nstrips + want - 1) / want);
+        int R = (int)(((long)batch * nr * nstrips + want - 1) / want);
         R = R < 4 ? 4 : (R > NNS_FD_RMAX ? NNS_FD_RMAX : R);
-        const int nbands = (nx + R - 1) / R;
+        const int nbands = (nr + R - 1) / R;
         const long nblocks = (long)batch * nbands * nstrips;
         if (nblocks > 0x7fffffffL) return fail(NNS_ERR_UNSUPPORTED, "fd_residual: grid too large");
         if (stencil == 5)
-            hipLaunchKernelGGL((fd_residual_vec_kernel<T, 5>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, R, nbands, nstrips, k);
+            hipLaunchKernelGGL((fd_residual_vec_kernel<T, 5>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, R, nbands, nstrips, k, hr);
         else
-            hipLaunchKernelGGL((fd_residual_vec_kernel<T, 9>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, R, nbands, nstrips, k);
+            hipLaunchKernelGGL((fd_residual_vec_kernel<T, 9>), dim3((unsigned)nblocks), dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, R, nbands, nstrips, k, hr);
     } else {
-        const dim3 grid((ny + 255) / 256, nx, batch);
+        if (nr > 65535 || batch > 65535) return fail(NNS_ERR_UNSUPPORTED, "fd_residual: ragged-size path is limited to 65535 rows and grids per launch");
+        const dim3 grid((ny + 255) / 256, nr, batch);
         if (stencil == 5)
-            hipLaunchKernelGGL((fd_residual_generic_kernel<T, 5>), grid, dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, k);
+            hipLaunchKernelGGL((fd_residual_generic_kernel<T, 5>), grid, dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, k, hr);
         else
-            hipLaunchKernelGGL((fd_residual_generic_kernel<T, 9>), grid, dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, k);
+            hipLaunchKernelGGL((fd_residual_generic_kernel<T, 9>), grid, dim3(256), 0, s, u, v, p, up, vp, ru, rv, rd, nx, ny, k, hr);
     }
     return check_launch("fd_residual");
 }
@@ -399,6 +419,23 @@ NNS_API int nns_fd_residual_f64(const double* u, const double* v, const double* 
                                 double* r_u, double* r_v, double* r_div, int batch, int nx, int ny, double dt, double dx, double dy,
                                 double rho, double nu, int stencil, void* stream) {
     return fd_residual<double>(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream));
+}
+
+NNS_API int nns_fd_residual_halo_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                     const float* halo_top, const float* halo_bot, float* r_u, float* r_v, float* r_div,
+                                     int batch, int nx_local, int ny, int row_begin, int row_end, double dt, double dx, double dy,
+                                     double rho, double nu, int stencil, void* stream) {
+    if (!halo_top || !halo_bot) return fail(NNS_ERR_INVALID_ARG, "fd_residual_halo: halo_top and halo_bot are required");
+    return fd_residual<float>(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx_local, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream),
+                              halo_top, halo_bot, row_begin, row_end);
+}
+NNS_API int nns_fd_residual_halo_f64(const double* u, const double* v, const double* p, const double* u_prev, const double* v_prev,
+                                     const double* halo_top, const double* halo_bot, double* r_u, double* r_v, double* r_div,
+                                     int batch, int nx_local, int ny, int row_begin, int row_end, double dt, double dx, double dy,
+                                     double rho, double nu, int stencil, void* stream) {
+    if (!halo_top || !halo_bot) return fail(NNS_ERR_INVALID_ARG, "fd_residual_halo: halo_top and halo_bot are required");
+    return fd_residual<double>(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx_local, ny, dt, dx, dy, rho, nu, stencil, reinterpret_cast<hipStream_t>(stream),
+                               halo_top, halo_bot, row_begin, row_end);
 }
 
 NNS_API int nns_fd_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,

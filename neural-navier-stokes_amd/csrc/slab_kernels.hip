@@ -1,0 +1,129 @@
+// Device-side packing for the slab decomposition of ONE grid over the GPUs of a node (nns/slab.py; SURVEY.md
+// section 8 (e): halo rows for the stencils, an all-to-all transpose for the spectral column pass).  The reference has
+// no multi-device path (src/neural_spectral/spectral_ode.py:155-156: one device); the north star is the spec.
+//
+// All four kernels are pure copies (HBM-bound, 8 B moved per element); what they buy is that a halo exchange or a
+// transpose costs ONE launch on each side of the collective instead of torch stack / permute / contiguous / cat passes:
+//   * gather_lines / scatter_lines: line `line_off + e * elem_stride`, e < len, of every outer block of up to 4 fields
+//     <-> one contiguous message [field][outer][len].  A row of a [B, nloc, ny] slab is (outer = B, stride 1); a column of
+//     a [nx, nyl] slab is (outer = 1, stride nyl).
+//   * transpose_pack: row slabs [F][B][nloc][ny] -> the all-to-all send buffer [dest][F][B][nloc][ny/P] (the column block of
+//     every destination contiguous); transpose_unpack: the received [src][F][B][nloc][ny/P] -> row slabs.
+//     (The column pass itself reads and writes the [src|dest][F][B][nloc][ny/P] layout in place: segmented rows,
+//     nns_spec_residual_xpass_seg_f32.)
+#include "nns_common.h"
+
+using namespace nns;
+
+namespace {
+
+template <typename T> struct Ptr4 { const T* p[4]; };
+template <typename T> struct MPtr4 { T* p[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_lines_kernel(Ptr4<T> src, T* __restrict__ dst, long nouter, long outer_stride, long line_off,
+                                                           long len, long elem_stride) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    const long o = blockIdx.y, f = blockIdx.z;
+    dst[(f * nouter + o) * len + e] = src.p[f][o * outer_stride + line_off + e * elem_stride];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_lines_kernel(const T* __restrict__ src, MPtr4<T> dst, long nouter, long outer_stride, long line_off,
+                                                            long len, long elem_stride) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    const long o = blockIdx.y, f = blockIdx.z;
+    dst.p[f][o * outer_stride + line_off + e * elem_stride] = src[(f * nouter + o) * len + e];
+}
+
+template <typename T>
+int lines(bool gather, const T* const* fields, int nfields, T* buf, long nouter, long outer_stride, long line_off, long len, long elem_stride,
+          hipStream_t s) {
+    if (!fields || !buf || nfields < 1 || nfields > 4 || nouter < 1 || nouter > 65535 || len < 1 || line_off < 0 || elem_stride < 1 || outer_stride < 0)
+        return fail(NNS_ERR_INVALID_ARG, "slab lines: bad args (nfields=%d nouter=%ld len=%ld)", nfields, nouter, len);
+    for (int f = 0; f < nfields; ++f)
+        if (!fields[f]) return fail(NNS_ERR_INVALID_ARG, "slab lines: field %d is NULL", f);
+    const dim3 grid((unsigned)((len + 255) / 256), (unsigned)nouter, (unsigned)nfields);
+    if (gather) {
+        Ptr4<T> q{};
+        for (int f = 0; f < nfields; ++f) q.p[f] = fields[f];
+        hipLaunchKernelGGL(gather_lines_kernel<T>, grid, dim3(256), 0, s, q, buf, nouter, outer_stride, line_off, len, elem_stride);
+    } else {
+        MPtr4<T> q{};
+        for (int f = 0; f < nfields; ++f) q.p[f] = const_cast<T*>(fields[f]);
+        hipLaunchKernelGGL(scatter_lines_kernel<T>, grid, dim3(256), 0, s, buf, q, nouter, outer_stride, line_off, len, elem_stride);
+    }
+    return check_launch(gather ? "slab_gather_lines" : "slab_scatter_lines");
+}
+
+// One thread per element of a row-slab field; consecutive threads = consecutive columns, so both sides move
+// contiguous runs of ny/P elements (512 B at 1024 / 8 in float32).
+template <typename T, bool PACK>
+__global__ __launch_bounds__(256) void transpose_kernel(Ptr4<T> rows_in, MPtr4<T> rows_out, T* __restrict__ buf, long B, long nloc, long ny, long P) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ny) return;
+    const long bi = blockIdx.y;                     // b * nloc + i
+    const long f = blockIdx.z, F = gridDim.z;
+    const long nyl = ny / P, d = j / nyl, jj = j - d * nyl;
+    const long row = bi * ny + j;                                            // [B][nloc][ny]
+    const long pk = ((d * F + f) * B * nloc + bi) * nyl + jj;                // [P][F][B][nloc][nyl]
+    if constexpr (PACK) buf[pk] = rows_in.p[f][row]; else rows_out.p[f][row] = buf[pk];
+}
+
+template <typename T>
+int transpose(bool pack, const T* const* fields, int nfields, T* buf, int B, int nloc, int ny, int P, hipStream_t s) {
+    if (!fields || !buf || nfields < 1 || nfields > 4 || B < 1 || nloc < 1 || ny < 1 || P < 1 || ny % P || (long)B * nloc > 0x7fffffffL)
+        return fail(NNS_ERR_INVALID_ARG, "slab transpose: bad args (nfields=%d B=%d nloc=%d ny=%d P=%d)", nfields, B, nloc, ny, P);
+    for (int f = 0; f < nfields; ++f)
+        if (!fields[f]) return fail(NNS_ERR_INVALID_ARG, "slab transpose: field %d is NULL", f);
+    const long bi = (long)B * nloc;
+    if (bi > 65535L * 32768L) return fail(NNS_ERR_UNSUPPORTED, "slab transpose: slab too tall");
+    // blockIdx.y is limited to 65535: fold the excess of B * nloc into blockIdx.x strides is not needed below 65535 rows;
+    // taller slabs go in chunks of 65535 row-lines
+    for (long r0 = 0; r0 < bi; r0 += 65535) {
+        const long nr = bi - r0 < 65535 ? bi - r0 : 65535;
+        Ptr4<T> in{}; MPtr4<T> out{};
+        for (int f = 0; f < nfields; ++f) { in.p[f] = fields[f] + r0 * ny; out.p[f] = const_cast<T*>(fields[f]) + r0 * ny; }
+        const dim3 grid((unsigned)((ny + 255) / 256), (unsigned)nr, (unsigned)nfields);
+        // the packed buffer is indexed by (b * nloc + i) too: shift its base by r0 lines of nyl elements
+        T* bshift = buf + r0 * (ny / P);
+        if (pack) hipLaunchKernelGGL((transpose_kernel<T, true>), grid, dim3(256), 0, s, in, out, bshift, (long)B, (long)nloc, (long)ny, (long)P);
+        else hipLaunchKernelGGL((transpose_kernel<T, false>), grid, dim3(256), 0, s, in, out, bshift, (long)B, (long)nloc, (long)ny, (long)P);
+    }
+    return check_launch(pack ? "slab_transpose_pack" : "slab_transpose_unpack");
+}
+
+}  // namespace
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+
+NNS_API int nns_slab_gather_lines_f32(const float* const* fields_host, int nfields, float* msg, long nouter, long outer_stride, long line_off,
+                                      long len, long elem_stride, void* stream) {
+    return lines<float>(true, fields_host, nfields, msg, nouter, outer_stride, line_off, len, elem_stride, S(stream));
+}
+NNS_API int nns_slab_gather_lines_f64(const double* const* fields_host, int nfields, double* msg, long nouter, long outer_stride, long line_off,
+                                      long len, long elem_stride, void* stream) {
+    return lines<double>(true, fields_host, nfields, msg, nouter, outer_stride, line_off, len, elem_stride, S(stream));
+}
+NNS_API int nns_slab_scatter_lines_f32(const float* msg, float* const* fields_host, int nfields, long nouter, long outer_stride, long line_off,
+                                       long len, long elem_stride, void* stream) {
+    return lines<float>(false, fields_host, nfields, const_cast<float*>(msg), nouter, outer_stride, line_off, len, elem_stride, S(stream));
+}
+NNS_API int nns_slab_scatter_lines_f64(const double* msg, double* const* fields_host, int nfields, long nouter, long outer_stride, long line_off,
+                                       long len, long elem_stride, void* stream) {
+    return lines<double>(false, fields_host, nfields, const_cast<double*>(msg), nouter, outer_stride, line_off, len, elem_stride, S(stream));
+}
+NNS_API int nns_slab_transpose_pack_f32(const float* const* fields_host, int nfields, float* send, int batch, int nloc, int ny, int nranks, void* stream) {
+    return transpose<float>(true, fields_host, nfields, send, batch, nloc, ny, nranks, S(stream));
+}
+NNS_API int nns_slab_transpose_pack_f64(const double* const* fields_host, int nfields, double* send, int batch, int nloc, int ny, int nranks, void* stream) {
+    return transpose<double>(true, fields_host, nfields, send, batch, nloc, ny, nranks, S(stream));
+}
+NNS_API int nns_slab_transpose_unpack_f32(const float* recv, float* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream) {
+    return transpose<float>(false, fields_host, nfields, const_cast<float*>(recv), batch, nloc, ny, nranks, S(stream));
+}
+NNS_API int nns_slab_transpose_unpack_f64(const double* recv, double* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream) {
+    return transpose<double>(false, fields_host, nfields, const_cast<double*>(recv), batch, nloc, ny, nranks, S(stream));
+}

@@ -272,6 +272,20 @@ int sor_rb_halfsweep(T* p, const T* C, void* err_bits, int nxl, int ny, int gi0,
     return check_launch("fd_sor_redblack_halfsweep");
 }
 
+// The chained form for slabs (nns/slab.py: SlabPressure): the half-sweep runs only if the PREVIOUS sweep's error *prev_bits
+// (already max-reduced over the ranks by the caller, on the stream) is > tol, exactly like the single-GPU chain above, so
+// a rank can enqueue many sweeps and their halo exchanges without reading anything back.
+template <typename T>
+int sor_rb_halfsweep_gated(T* p, const T* C, void* err_bits, const void* prev_bits, double tol, int nxl, int ny, int gi0, int colour,
+                           double dx, double dy, double beta, hipStream_t s) {
+    if (!p || !C || !err_bits || !prev_bits || nxl < 3 || ny < 3 || (colour != 0 && colour != 1) || gi0 < 0)
+        return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack_halfsweep_gated: bad args (nxl=%d ny=%d gi0=%d colour=%d)", nxl, ny, gi0, colour);
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
+    using U = typename BitsOf<T>::U;
+    launch_halfsweep<T>(p, C, static_cast<U*>(err_bits), static_cast<const U*>(prev_bits), 0, 1, nxl, ny, gi0, colour, k, s);
+    return check_launch("fd_sor_redblack_halfsweep_gated");
+}
+
 // slots[b][0] = the bit pattern of 1 (the reference's initial err, :183), slots[b][1 .. cap] = 0
 template <typename T>
 __global__ void sor_rb_init_kernel(typename BitsOf<T>::U* __restrict__ slots, long n, int per_grid) {
@@ -361,4 +375,13 @@ NNS_API int nns_fd_sor_redblack_halfsweep_f32(float* p, const float* C, void* er
 NNS_API int nns_fd_sor_redblack_halfsweep_f64(double* p, const double* C, void* err_bits, int nxl, int ny, int gi0, int colour,
                                               double dx, double dy, double beta, void* stream) {
     return sor_rb_halfsweep<double>(p, C, err_bits, nxl, ny, gi0, colour, dx, dy, beta, reinterpret_cast<hipStream_t>(stream));
+}
+
+NNS_API int nns_fd_sor_redblack_halfsweep_gated_f32(float* p, const float* C, void* err_bits, const void* prev_err_bits, double tol,
+                                                    int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, void* stream) {
+    return sor_rb_halfsweep_gated<float>(p, C, err_bits, prev_err_bits, tol, nxl, ny, gi0, colour, dx, dy, beta, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_redblack_halfsweep_gated_f64(double* p, const double* C, void* err_bits, const void* prev_err_bits, double tol,
+                                                    int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, void* stream) {
+    return sor_rb_halfsweep_gated<double>(p, C, err_bits, prev_err_bits, tol, nxl, ny, gi0, colour, dx, dy, beta, reinterpret_cast<hipStream_t>(stream));
 }

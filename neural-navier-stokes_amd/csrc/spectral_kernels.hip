@@ -93,6 +93,10 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
 // j+1 neighbours of u and v are already in its registers (adjacent lane, or the adjacent 64-column slot at the wave's
 // ends) and the rows i-1 / i+1 are re-read from L2 -- the stencil back-end then costs no second pass over the inputs.
 struct FdK { float inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2; };
+// Row slabs of a grid sharded over ranks (nns/slab.py): the stencil's row above local row 0 / below local row nx-1 comes from
+// the neighbour rank's edge rows, delivered as [u, v, p][grid][N] messages (top / bot; stride = grids * N).  NULL: the
+// rows wrap around inside the local grid (single process).
+struct HaloK { const float* top; const float* bot; long fstride; };
 #ifndef NNS_YPASS_NT
 #define NNS_YPASS_NT 1            // non-temporal hints on the fused row pass's write-once outputs and read-once streams (0.84 -> 0.78 ms)
 #endif
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                                                                    const float* __restrict__ vp, float* __restrict__ ru,
                                                                    float* __restrict__ rv, float* __restrict__ rd,
                                                                    float* __restrict__ fu, float* __restrict__ fv, float* __restrict__ fd,
-                                                                   int nx, FdK fk, long nrows, SpecK k) {
+                                                                   int nx, FdK fk, long nrows, SpecK k, HaloK hk) {
     using L = SpecLds<N, TF>;
     constexpr int TPF = L::TPF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -167,7 +171,10 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
     // Software pipeline: the NEXT line's u, v, p are requested when the inverse transforms start (registers are
     // slack there: the float64 spectra are dead) and are consumed at the top of the next iteration.
     float nu[16], nv[16], np[16];
-    long it = blockIdx.x;
+#ifndef NNS_YPASS_XCD
+#define NNS_YPASS_XCD 0
+#endif
+    long it = NNS_YPASS_XCD ? (long)xcd_remap(blockIdx.x, gridDim.x) : (long)blockIdx.x;
     if (it >= niter) return;
     {
         const size_t b0 = line_base(it);
@@ -248,6 +255,8 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
             const size_t bc = (size_t)row * N;
             const float* um_p = u + bm; const float* un_p = u + bp; const float* vm_p = v + bm; const float* vn_p = v + bp;
             const float* pm_p = p + bm; const float* pn_p = p + bp;
+            if (hk.top && ii == 0) { const float* h = hk.top + (size_t)gi * N + tidv; um_p = h; vm_p = h + hk.fstride; pm_p = h + 2 * hk.fstride; }
+            if (hk.bot && ii == nx - 1) { const float* h = hk.bot + (size_t)gi * N + tidv; un_p = h; vn_p = h + hk.fstride; pn_p = h + 2 * hk.fstride; }
             const float* pl_p = p + bc + tidv - 1;                          // column - 1: wraps only for column 0 (slot 0 of lane 0)
             const float* pr_p = p + bc + tidv + 1;                          // column + 1: wraps only for column N-1 (slot 15 of lane 63)
             const float* pl0_p = p + bc + ((tidv + N - 1) & (N - 1));
@@ -292,11 +301,20 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
 // ------------------------------------------------------------------------------------------
 // PREFETCH = false falls back to loading each tile at the top of its own iteration (instantiations whose
 // register allocation does not fit the extra 48 staging registers without spilling).
-template <int N, typename TF, bool PREFETCH>
+// SEG (slab-decomposed grids, nns/slab.py): the rows of a column slab arrive from the all-to-all in blocks of 2^shift rows
+// per source rank, [src][field][grid][2^shift][ny]; row r of a grid then starts at (r >> shift) * stride + (r & mask) * ny
+// and consecutive grids are 2^shift * ny apart.  The column pass reads that layout and writes its partials in the same
+// layout (= the send buffer of the return all-to-all), so no permuting copy stands on either side of it.
+struct SegK { int shift; long stride; };
+template <int N, typename TF, bool PREFETCH, bool SEG = false>
 __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                                    const float* __restrict__ p, float* __restrict__ ru,
                                                                    float* __restrict__ rv, float* __restrict__ rd,
-                                                                   int ny, int tiles_per_grid, long ntiles, SpecK k) {
+                                                                   int ny, int tiles_per_grid, long ntiles, SpecK k, SegK sg) {
+    auto row_off = [&](int r) -> size_t {
+        if constexpr (SEG) return (size_t)(r >> sg.shift) * sg.stride + (size_t)(r & ((1 << sg.shift) - 1)) * ny;
+        else return (size_t)r * ny;
+    };
     using L = SpecLds<N, TF>;
     constexpr int TPF = L::TPF, CW = L::LINES, SF = L::STAGE_F;
     constexpr int ROWS_PER_IT = kSpecThreads / CW;
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
         // neighbouring tiles -> same XCD (shared lines); tiles are walked from the LAST grid to the first (see launch_xpass)
         const long lt = NNS_XPASS_REVERSE ? ntiles - 1 - (long)xcd_remap((unsigned)t, (unsigned)ntiles) : (long)xcd_remap((unsigned)t, (unsigned)ntiles);
         j0 = (int)(lt % tiles_per_grid) * CW;
-        g = (size_t)(lt / tiles_per_grid) * N * ny;
+        g = (size_t)(lt / tiles_per_grid) * (SEG ? ((size_t)ny << sg.shift) : (size_t)N * ny);
     };
     auto issue_loads = [&](long t) {
         int tx = threadIdx.x;
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
         const bool ok = j0 + cc < ny;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const size_t c = g + (size_t)(cr + ROWS_PER_IT * i) * ny + j0 + cc;
+            const size_t c = g + row_off(cr + ROWS_PER_IT * i) + j0 + cc;
             su[i] = ok ? u[c] : 0.f; sv[i] = ok ? v[c] : 0.f; sp[i] = ok ? p[c] : 0.f;
         }
     };
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
             asm volatile("" : "+v"(ty));
             const int cc = ty % CW, cr = ty / CW;
             const int col = j0n + cc < ny ? j0n + cc : ny - 1;                // clamped column: no mask needed on a load
-            const size_t c = gn + (size_t)(cr + ROWS_PER_IT * i) * ny + col;
+            const size_t c = gn + row_off(cr + ROWS_PER_IT * i) + col;
             su[i] = u[c]; sv[i] = v[c]; sp[i] = p[c];
         };
         auto hook = [&](auto sc) {
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const int r = cr2 + ROWS_PER_IT * i;
-                    const size_t c = g + (size_t)r * ny + j0 + cc2;
+                    const size_t c = g + row_off(r) + j0 + cc2;
                     ru[c] = st[0 * SF + r];
                     rv[c] = st[1 * SF + r];
                     rd[c] = st[2 * SF + r];
@@ -427,14 +445,15 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
 // y-pass starts on the partials (and inputs) the x-pass touched last -- part of them is still in the 256 MB Infinity
 // Cache -- and an x-pass that follows a forward-streaming kernel over the same inputs (the FD residual in bench.py)
 // starts on what that kernel read last.  Same-box A/B at 1024^2 x 64: y-pass 0.619 -> 0.589 ms, x-pass 0.614 -> 0.606.
-template <int N, typename TF>
-int launch_xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int ny, const SpecK& k, hipStream_t s) {
+template <int N, typename TF, bool SEG = false>
+int launch_xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int ny, const SpecK& k, hipStream_t s,
+                 const SegK& sg = SegK{}) {
     using L = SpecLds<N, TF>;
     const int tiles_per_grid = (ny + L::LINES - 1) / L::LINES;
     const long ntiles = (long)batch * tiles_per_grid;
     // prefetch is disabled where hipcc (ROCm 7.2) spills with it: checked with -Rpass-analysis=kernel-resource-usage
     constexpr bool PF = !((N == 128 && sizeof(TF) == 4) || N == 256);
-    auto kern = spec_xpass_kernel<N, TF, PF>;
+    auto kern = spec_xpass_kernel<N, TF, PF, SEG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
@@ -443,14 +462,14 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
     }
     const long gmax = spec_grid_cap();
     const unsigned grid = (unsigned)(ntiles < gmax ? ntiles : gmax);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, ru, rv, rd, ny, tiles_per_grid, ntiles, k);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, ru, rv, rd, ny, tiles_per_grid, ntiles, k, sg);
     return check_launch("spec_residual_xpass");
 }
 
 template <int N, typename TF, bool FUSE_FD = false>
 int launch_ypass(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
                  long nrows, const SpecK& k, hipStream_t s, float* fu = nullptr, float* fv = nullptr, float* fd = nullptr, int nx = 1,
-                 const FdK& fk = FdK{}) {
+                 const FdK& fk = FdK{}, const HaloK& hk = HaloK{}) {
     using L = SpecLds<N, TF>;
     auto kern = spec_ypass_kernel<N, TF, FUSE_FD>;
     static bool attr_set = false;
@@ -462,17 +481,27 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
     const long niter = (nrows + L::LINES - 1) / L::LINES;
     const long gmax = spec_grid_cap();
     const unsigned grid = (unsigned)(niter < gmax ? niter : gmax);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, nrows, k);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, nrows, k, hk);
     return check_launch("spec_residual_ypass");
 }
 
 int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
-          double Lx, double rho, double nu, int precise, hipStream_t s) {
+          double Lx, double rho, double nu, int precise, hipStream_t s, int seg_rows = 0, long seg_stride = 0) {
     if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
     if (!pow2_in_range(nx)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_xpass: nx=%d must be a power of two in [64, 1024]", nx);
     if (Lx == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: Lx, rho must be non-zero");
     const double ks = 2.0 * M_PI / Lx;
     SpecK k{ks / nx, ks / (rho * nx), nu * ks * ks / nx, 0.f};
+    if (seg_rows) {
+        if (seg_rows < 1 || seg_rows > nx || (seg_rows & (seg_rows - 1)) || seg_stride < (long)seg_rows * ny)
+            return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass_seg: seg_rows=%d must be a power of two <= nx=%d and seg_stride=%ld >= seg_rows * ny", seg_rows, nx, seg_stride);
+        SegK sg{__builtin_ctz((unsigned)seg_rows), seg_stride};
+        return dispatch_n(nx, [&](auto n) {
+            constexpr int N = decltype(n)::value;
+            return precise ? launch_xpass<N, double, true>(u, v, p, ru, rv, rd, batch, ny, k, s, sg)
+                           : launch_xpass<N, float, true>(u, v, p, ru, rv, rd, batch, ny, k, s, sg);
+        });
+    }
     return dispatch_n(nx, [&](auto n) {
         constexpr int N = decltype(n)::value;
         return precise ? launch_xpass<N, double>(u, v, p, ru, rv, rd, batch, ny, k, s)
@@ -498,22 +527,25 @@ int ypass(const float* u, const float* v, const float* p, const float* up, const
 // FD 5-point + spectral residual of the same inputs: spectral x-pass, then the row pass with the stencil fused in.
 int residual_both(const float* u, const float* v, const float* p, const float* up, const float* vp, float* fu, float* fv, float* fd,
                   float* ru, float* rv, float* rd, int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
-                  int precise, hipStream_t s, bool with_xpass) {
+                  int precise, hipStream_t s, bool with_xpass, const float* halo_top = nullptr, const float* halo_bot = nullptr) {
     if (!u || !v || !p || !up || !vp || !fu || !fv || !fd || !ru || !rv || !rd || batch < 1 || nx < 3)
         return fail(NNS_ERR_INVALID_ARG, "residual_both: bad args");
-    if (!pow2_in_range(ny) || !pow2_in_range(nx)) return fail(NNS_ERR_UNSUPPORTED, "residual_both: nx=%d, ny=%d must be powers of two in [64, 1024]", nx, ny);
+    const bool slab = halo_top || halo_bot;               // a row slab: nx is the LOCAL row count (any value >= 3), only ny is transformed here
+    if (slab && (!halo_top || !halo_bot || with_xpass)) return fail(NNS_ERR_INVALID_ARG, "residual_both: a row slab needs both halo messages and the row pass only");
+    if (!pow2_in_range(ny) || (!slab && !pow2_in_range(nx))) return fail(NNS_ERR_UNSUPPORTED, "residual_both: nx=%d, ny=%d must be powers of two in [64, 1024]", nx, ny);
     if (Ly == 0 || rho == 0 || dt == 0 || Lx == 0) return fail(NNS_ERR_INVALID_ARG, "residual_both: Lx, Ly, rho, dt must be non-zero");
     if (with_xpass) {
         if (int rc = xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, precise, s)) return rc;
     }
-    const double ks = 2.0 * M_PI / Ly, dx = Lx / nx, dy = Ly / ny;
+    const double ks = 2.0 * M_PI / Ly, dx = slab ? Lx : Lx / nx, dy = Ly / ny;          // a row slab passes the grid spacing itself in Lx
     const SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy)};
     const long nrows = (long)batch * nx;
+    const HaloK hk{halo_top, halo_bot, (long)batch * ny};
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        return precise ? launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk)
-                       : launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk);
+        return precise ? launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk)
+                       : launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk);
     });
 }
 
@@ -532,9 +564,22 @@ NNS_API int nns_residual_both_rowpass_f32(const float* u, const float* v, const 
     return residual_both(u, v, p, u_prev, v_prev, fd_r_u, fd_r_v, fd_r_div, sp_r_u, sp_r_v, sp_r_div, batch, nx, ny, dt, Lx, Ly, rho, nu, precise, S(stream), false);
 }
 
+NNS_API int nns_residual_both_rowpass_halo_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                               const float* halo_top, const float* halo_bot,
+                                               float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                                               int batch, int nx_local, int ny, double dt, double dx, double Ly, double rho, double nu, int precise, void* stream) {
+    if (!halo_top || !halo_bot) return fail(NNS_ERR_INVALID_ARG, "residual_both_rowpass_halo: halo_top and halo_bot are required");
+    return residual_both(u, v, p, u_prev, v_prev, fd_r_u, fd_r_v, fd_r_div, sp_r_u, sp_r_v, sp_r_div, batch, nx_local, ny, dt, dx, Ly, rho, nu, precise,
+                         S(stream), false, halo_top, halo_bot);
+}
 NNS_API int nns_spec_residual_xpass_f32(const float* u, const float* v, const float* p, float* r_u, float* r_v, float* r_div,
                                         int batch, int nx, int ny, double Lx, double rho, double nu, int precise, void* stream) {
     return xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, precise, S(stream));
+}
+NNS_API int nns_spec_residual_xpass_seg_f32(const float* u, const float* v, const float* p, float* r_u, float* r_v, float* r_div,
+                                            int batch, int nx, int ny, int seg_rows, long seg_stride, double Lx, double rho, double nu, int precise, void* stream) {
+    if (seg_rows < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass_seg: seg_rows must be >= 1");
+    return xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, precise, S(stream), seg_rows, seg_stride);
 }
 NNS_API int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
                                         float* r_u, float* r_v, float* r_div, int batch, int nx, int ny, double dt, double Ly,

@@ -1,0 +1,107 @@
+"""Message transport of the slab-decomposed paths (nns/slab.py) over a `torch.distributed` group, one process per GPU.
+
+  * backend "nccl" (= RCCL over xGMI on a GPU node): device buffers go to the collective as they are; every call is
+    enqueued stream-ordered and returns a handle whose wait() makes the CURRENT STREAM wait (no host block), so compute
+    enqueued between the call and wait() overlaps the transfer.
+  * backend "gloo" (CPU tests, and the two-ranks-on-one-GPU rehearsal of the HIP path on a one-GPU box): gloo moves host
+    memory, so device tensors are staged through host buffers around a blocking collective; wait() is then a no-op.
+
+xGMI is point-to-point: a halo exchange talks to the two ring neighbours only (their two direct links); the transpose is ONE
+all-to-all (all seven links of a GPU at once).
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Done(object):
+    def wait(self):
+        return None
+
+
+class _Works(object):
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+class Transport(object):
+    def __init__(self, group=None):
+        self.group = group
+        self.P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else 'none'
+
+    def _staged(self, t):
+        return t.is_cuda and self.backend != 'nccl'
+
+    # ------------------------------------------------------------------ point to point
+    def sendrecv(self, sends, recvs):
+        """sends / recvs: lists of (tensor, peer) in POSTING ORDER (two messages between one pair of ranks are matched in
+        that order -- with two ranks both ring neighbours are the same peer).  Returns a handle; the receive buffers are
+        valid after handle.wait()."""
+        if self.P == 1 or not (sends or recvs):
+            return _Done()
+        if any(self._staged(t) for t, _ in sends + recvs):
+            hs = [(t.cpu(), peer) for t, peer in sends]
+            hr = [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
+            reqs = [dist.isend(t, peer, group=self.group) for t, peer in hs] + [dist.irecv(t, peer, group=self.group) for t, peer in hr]
+            for q in reqs:
+                q.wait()
+            for (dst, _), (src, _) in zip(recvs, hr):
+                dst.copy_(src)
+            return _Done()
+        ops = [dist.P2POp(dist.isend, t, peer, self.group) for t, peer in sends] + [dist.P2POp(dist.irecv, t, peer, self.group) for t, peer in recvs]
+        return _Works(dist.batch_isend_irecv(ops))
+
+    def ring_exchange(self, first, last, from_down, from_up, wrap=True):
+        """Every rank sends `first` to the rank before it and `last` to the rank after it; from_down receives the next
+        rank's `first`, from_up the previous rank's `last`.  wrap=False: the ends of the chain have no neighbour there
+        (pass None for the buffers that do not exist)."""
+        P, r = self.P, self.rank
+        if P == 1:
+            if wrap:
+                from_up.copy_(last), from_down.copy_(first)
+            return _Done()
+        up, down = (r - 1) % P, (r + 1) % P
+        has_up, has_down = wrap or r > 0, wrap or r < P - 1
+        sends, recvs = [], []
+        if has_up:
+            sends.append((first, up))
+        if has_down:
+            sends.append((last, down))
+        # posting order of the receives = the peers' sending order (their `first`, then their `last`)
+        if has_down:
+            recvs.append((from_down, down))
+        if has_up:
+            recvs.append((from_up, up))
+        return self.sendrecv(sends, recvs)
+
+    # ------------------------------------------------------------------ collectives
+    def all_to_all(self, recv, send):
+        """recv[src] <- rank src's send[this rank] (equal splits along dim 0)."""
+        if self.P == 1:
+            recv.copy_(send)
+            return _Done()
+        if self._staged(send):
+            hs = send.cpu()
+            hr = torch.empty_like(hs)
+            dist.all_to_all_single(hr, hs, group=self.group)
+            recv.copy_(hr)
+            return _Done()
+        w = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return _Works([w])
+
+    def all_reduce_(self, t, op):
+        """In place, stream-ordered on nccl (no host synchronisation)."""
+        if self.P == 1:
+            return t
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+            return t
+        dist.all_reduce(t, op=op, group=self.group)
+        return t

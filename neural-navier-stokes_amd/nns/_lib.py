@@ -25,7 +25,8 @@ class BcList(C.Structure):
 
 _lib = None
 
-_P, _I, _D, _SZ = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_P, _I, _D, _SZ, _L = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_long
+_PP = C.POINTER(C.c_void_p)          # host array of device pointers
 _BCP = C.POINTER(BcList)
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); the fd/bc ops exist as _f32 and _f64
@@ -47,6 +48,12 @@ _DUAL = {
     'nns_fd_residual': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_fd_residual_bwd': [_P] * 10 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_coarsen': [_P] * 6 + [_I] * 6 + [_P],
+    'nns_fd_sor_redblack_halfsweep_gated': [_P] * 4 + [_D] + [_I] * 4 + [_D] * 3 + [_P],
+    'nns_fd_residual_halo': [_P] * 10 + [_I] * 5 + [_D] * 5 + [_I, _P],
+    'nns_slab_gather_lines': [_PP, _I, _P] + [_L] * 5 + [_P],
+    'nns_slab_scatter_lines': [_P, _PP, _I] + [_L] * 5 + [_P],
+    'nns_slab_transpose_pack': [_PP, _I, _P] + [_I] * 4 + [_P],
+    'nns_slab_transpose_unpack': [_P, _PP, _I] + [_I] * 4 + [_P],
 }
 _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
@@ -54,6 +61,8 @@ _SINGLE = {
     'nns_residual_both_rowpass_f32': [_P] * 11 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_bwd_f32': [_P] * 10 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_xpass_f32': [_P] * 6 + [_I] * 3 + [_D] * 3 + [_I, _P],
+    'nns_spec_residual_xpass_seg_f32': [_P] * 6 + [_I] * 4 + [_L] + [_D] * 3 + [_I, _P],
+    'nns_residual_both_rowpass_halo_f32': [_P] * 13 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_spec_derivs_f32': [_P] * 4 + [_I] * 3 + [_D, _D, _I, _P],
     'nns_spec_rfft2_f32': [_P, _P, _I, _I, _I, _P],
@@ -72,6 +81,7 @@ _SINGLE = {
     'nns_basis_expand_bwd_f32': [_P] * 5 + [_I] * 4 + [_P],
     'nns_basis_loss_fwd_f32': [_P] * 4 + [_I] * 4 + [_P],
     'nns_basis_loss_bwd_f32': [_P] * 3 + [C.c_float] + [_P] * 2 + [_I] * 4 + [_P],
+    'nns_basis_loss_fused_f32': [_P] * 6 + [_I] * 4 + [_P],
     'nns_fd_predictor_adi_workspace': [_I, _I, _I, _I],
     'nns_fd_sor_workspace': [_I, _I, _I, _I],
     'nns_fd_sor_redblack_workspace': [_I, _I, _I, _I, _I],

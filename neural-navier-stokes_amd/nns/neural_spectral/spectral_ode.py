@@ -50,22 +50,41 @@ class _BasisExpandFn(torch.autograd.Function):
         return ops.basis_expand_bwd(coeff, basis, g.contiguous())
 
 
-class _BasisLossFn(torch.autograd.Function):
-    """|| sum_k coeff basis - obs ||_2 (spectral_ode.py:182) without materialising the prediction."""
+class _BasisSumsqFn(torch.autograd.Function):
+    """sum (sum_k coeff basis - obs)^2 as a float64 device scalar, without materialising the prediction.  When a gradient
+    will be wanted the forward sweep also accumulates d(sumsq / 2) / d(coeff, basis) (nns_basis_loss_fused_f32): the
+    observations -- the only large stream -- cross HBM ONCE per training step, and the backward is two small scalings on the
+    device (no host read of the loss)."""
 
     @staticmethod
     def forward(ctx, coeff, basis, obs):
         coeff, basis, obs = coeff.contiguous(), basis.contiguous(), obs.contiguous()
-        loss = torch.sqrt(ops.basis_loss_fwd(coeff, basis, obs)).to(torch.float32).reshape(())
-        ctx.save_for_backward(coeff, basis, obs, loss)
-        return loss
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            ss, gc, gb = ops.basis_loss_fused(coeff, basis, obs)
+            ctx.save_for_backward(gc, gb)
+        else:
+            ss = ops.basis_loss_fwd(coeff, basis, obs)
+        return ss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        coeff, basis, obs, loss = ctx.saved_tensors
-        scale = float((g / loss).item())
-        gc, gb = ops.basis_loss_bwd(coeff, basis, obs, scale)
-        return gc, gb, None
+        gc, gb = ctx.saved_tensors
+        s = (2.0 * g).to(torch.float32)                       # d sumsq = 2 * d(sumsq / 2)
+        return gc * s, gb * s, None
+
+
+def basis_sumsq(coeff, basis, obs):
+    return _BasisSumsqFn.apply(coeff, basis, obs)
+
+
+def basis_norm_loss(coeff, basis, obs):
+    """|| sum_k coeff basis - obs ||_2 (spectral_ode.py:182), float32 scalar."""
+    return torch.sqrt(_BasisSumsqFn.apply(coeff, basis, obs)).to(torch.float32)
+
+
+class _BasisLossFn(object):
+    """Kept name of the fused training objective (used by spectral_ode2 / spectral_rnn): see basis_norm_loss."""
+    apply = staticmethod(basis_norm_loss)
 
 
 def _require_device(what, *ts):
@@ -115,7 +134,16 @@ class PDEFunc(nn.Module):
         coeff, basis = self._coeff(mb, nt), self._basis()
         o = obs.reshape(nt * mb, 3, self.nx * self.ny)
         _require_device('basis loss', coeff, basis, o)
-        return _BasisLossFn.apply(coeff, basis, o)
+        return basis_norm_loss(coeff, basis, o)
+
+    def sumsq(self, grid0, t, obs):
+        """The SQUARE of `loss` as a float64 scalar: additive over shards of the ensemble, which is what data-parallel
+        training all-reduces (nns.data_parallel.norm_loss_step)."""
+        mb, nt = grid0.size(0), t.size(0)
+        coeff, basis = self._coeff(mb, nt), self._basis()
+        o = obs.reshape(nt * mb, 3, self.nx * self.ny)
+        _require_device('basis loss', coeff, basis, o)
+        return basis_sumsq(coeff, basis, o)
 
     def basis_weight_mat(self):
         W = []

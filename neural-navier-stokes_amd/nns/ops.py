@@ -151,6 +151,17 @@ def fd_sor_redblack_halfsweep_(p, C, err, gi0, colour, dx, dy, beta):
     return err
 
 
+def fd_sor_redblack_halfsweep_gated_(p, C, err, prev_err, tol, gi0, colour, dx, dy, beta):
+    """The half-sweep as one link of a pre-enqueued chain (nns_fd_sor_redblack_halfsweep_gated_*): it runs only if the
+    one-element device tensor prev_err (the previous sweep's error, already max-reduced over the ranks) is > tol."""
+    if p.dim() != 2 or p.shape != C.shape or not p.is_cuda or not p.is_contiguous() or not C.is_contiguous():
+        raise ValueError("fd_sor_redblack_halfsweep_gated_: p, C must be contiguous 2-D device tensors of one shape")
+    suf = '_f32' if p.dtype == torch.float32 else '_f64'
+    _call('nns_fd_sor_redblack_halfsweep_gated', suf, _p(p), _p(C), _p(err), _p(prev_err), float(tol), p.shape[0], p.shape[1], int(gi0), int(colour),
+          dx, dy, beta, _stream())
+    return err
+
+
 def fd_correction(ui, vi, p, dt, dx, dy):
     suf, (B, nx, ny) = _chk(ui, vi, p)
     u, v = torch.empty_like(ui), torch.empty_like(vi)
@@ -206,6 +217,20 @@ def fd_residual(u, v, p, u_prev, v_prev, dt, dx, dy, rho, nu, stencil=5, out=Non
     ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
     _call('nns_fd_residual', suf, _p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
           dt, dx, dy, rho, nu, int(stencil), _stream())
+    return ru, rv, rd
+
+
+def fd_residual_halo(u, v, p, u_prev, v_prev, halo_top, halo_bot, dt, dx, dy, rho, nu, stencil=5, rows=None, out=None):
+    """fd_residual on local rows `rows` = (begin, end) of a row slab [B, nloc, ny] whose rows -1 / nloc are the
+    [3, B, ny] messages halo_top / halo_bot (nns_fd_residual_halo_*)."""
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
+    for h in (halo_top, halo_bot):
+        if not (h.is_cuda and h.is_contiguous() and h.dtype == u.dtype and tuple(h.shape) == (3, B, ny)):
+            raise ValueError("fd_residual_halo: halo messages must be contiguous [3, %d, %d] device tensors of the fields' dtype" % (B, ny))
+    ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
+    r0, r1 = rows if rows is not None else (0, nx)
+    _call('nns_fd_residual_halo', suf, _p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(halo_top), _p(halo_bot), _p(ru), _p(rv), _p(rd),
+          B, nx, ny, int(r0), int(r1), dt, dx, dy, rho, nu, int(stencil), _stream())
     return ru, rv, rd
 
 
@@ -276,6 +301,96 @@ def spec_residual_xpass(u, v, p, Lx, rho, nu, precise=True, out=None):
     return ru, rv, rd
 
 
+def spec_residual_xpass_seg(recv, send, B, nx, nyl, seg_rows, Lx, rho, nu, precise=True):
+    """The column pass on the RECEIVE buffer of the slab all-to-all, recv [P, 3, B, seg_rows, nyl] (u, v, p from every source
+    rank), writing its three partials into `send` of the same layout (the send buffer of the return all-to-all):
+    nns_spec_residual_xpass_seg_f32."""
+    _f32(recv, send)
+    if recv.shape != send.shape or recv.dim() != 5 or recv.shape[1] != 3 or recv.shape[0] * seg_rows != nx or tuple(recv.shape[2:]) != (B, seg_rows, nyl):
+        raise ValueError("spec_residual_xpass_seg: buffers must be [P, 3, %d, %d, %d] with P * seg_rows = nx = %d, got %s" % (B, seg_rows, nyl, nx, tuple(recv.shape)))
+    fs = B * seg_rows * nyl                  # one field of one source rank
+    e = recv.element_size()
+    q = lambda t, f: t.data_ptr() + f * fs * e
+    check(_lib.lib().nns_spec_residual_xpass_seg_f32(q(recv, 0), q(recv, 1), q(recv, 2), q(send, 0), q(send, 1), q(send, 2), B, nx, nyl,
+                                                     int(seg_rows), 3 * fs, Lx, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_xpass_seg_f32')
+    return send
+
+
+def residual_both_rowpass_halo(u, v, p, u_prev, v_prev, halo_top, halo_bot, sp_partials, dt, dx, Ly, rho, nu, precise=True, out_fd=None):
+    """The fused row pass on a row slab (nns_residual_both_rowpass_halo_f32): sp_partials holds the column pass's partials on
+    entry and the spectral residual on return; returns ((fd r_u, r_v, r_div), sp_partials)."""
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev, *sp_partials)
+    if suf != '_f32':
+        raise TypeError("residual_both_rowpass_halo: float32 fields")
+    for h in (halo_top, halo_bot):
+        if not (h.is_cuda and h.is_contiguous() and h.dtype == u.dtype and tuple(h.shape) == (3, B, ny)):
+            raise ValueError("residual_both_rowpass_halo: halo messages must be contiguous [3, %d, %d] float32 device tensors" % (B, ny))
+    fo = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
+    so = sp_partials
+    check(_lib.lib().nns_residual_both_rowpass_halo_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(halo_top), _p(halo_bot),
+                                                        _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny,
+                                                        dt, dx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_residual_both_rowpass_halo_f32')
+    return fo, so
+
+
+# ----------------------------------------------------------------------------- slab message packing (nns/slab.py)
+def _ptr_array(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _slab_fields(fields, what):
+    t0 = fields[0]
+    if not 1 <= len(fields) <= 4:
+        raise ValueError("%s: 1 to 4 fields per message" % what)
+    for t in fields:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype == t0.dtype and t.shape == t0.shape):
+            raise ValueError("%s: fields must be contiguous device tensors of one shape and dtype" % what)
+    return _suffix(t0)
+
+
+def slab_gather_lines(fields, msg, nouter, outer_stride, line_off, length, elem_stride=1):
+    """msg[f, o, e] = fields[f].flat[o * outer_stride + line_off + e * elem_stride] (one launch, nns_slab_gather_lines_*)."""
+    suf = _slab_fields(fields, 'slab_gather_lines')
+    if not (msg.is_cuda and msg.is_contiguous() and msg.dtype == fields[0].dtype and msg.numel() == len(fields) * nouter * length):
+        raise ValueError("slab_gather_lines: msg must hold nfields * nouter * len elements")
+    if (nouter - 1) * outer_stride + line_off + (length - 1) * elem_stride >= fields[0].numel():
+        raise ValueError("slab_gather_lines: line runs past the end of the field")
+    _call('nns_slab_gather_lines', suf, _ptr_array(fields), len(fields), _p(msg), nouter, outer_stride, line_off, length, elem_stride, _stream())
+    return msg
+
+
+def slab_scatter_lines(msg, fields, nouter, outer_stride, line_off, length, elem_stride=1):
+    """The reverse of slab_gather_lines: writes the message's lines into the fields (nns_slab_scatter_lines_*)."""
+    suf = _slab_fields(fields, 'slab_scatter_lines')
+    if not (msg.is_cuda and msg.is_contiguous() and msg.dtype == fields[0].dtype and msg.numel() == len(fields) * nouter * length):
+        raise ValueError("slab_scatter_lines: msg must hold nfields * nouter * len elements")
+    if (nouter - 1) * outer_stride + line_off + (length - 1) * elem_stride >= fields[0].numel():
+        raise ValueError("slab_scatter_lines: line runs past the end of the field")
+    _call('nns_slab_scatter_lines', suf, _p(msg), _ptr_array(fields), len(fields), nouter, outer_stride, line_off, length, elem_stride, _stream())
+    return fields
+
+
+def slab_transpose_pack(fields, send, P):
+    """Row slabs fields[f] [B, nloc, ny] -> send [P, F, B, nloc, ny / P] (nns_slab_transpose_pack_*)."""
+    suf = _slab_fields(fields, 'slab_transpose_pack')
+    B, nloc, ny = fields[0].shape
+    if not (send.is_cuda and send.is_contiguous() and send.dtype == fields[0].dtype and tuple(send.shape) == (P, len(fields), B, nloc, ny // P) and ny % P == 0):
+        raise ValueError("slab_transpose_pack: send must be [%d, %d, %d, %d, %d]" % (P, len(fields), B, nloc, ny // P))
+    _call('nns_slab_transpose_pack', suf, _ptr_array(fields), len(fields), _p(send), B, nloc, ny, P, _stream())
+    return send
+
+
+def slab_transpose_unpack(recv, fields, P):
+    """recv [P, F, B, nloc, ny / P] -> row slabs fields[f] [B, nloc, ny] (nns_slab_transpose_unpack_*)."""
+    suf = _slab_fields(fields, 'slab_transpose_unpack')
+    B, nloc, ny = fields[0].shape
+    if not (recv.is_cuda and recv.is_contiguous() and recv.dtype == fields[0].dtype and tuple(recv.shape) == (P, len(fields), B, nloc, ny // P) and ny % P == 0):
+        raise ValueError("slab_transpose_unpack: recv must be [%d, %d, %d, %d, %d]" % (P, len(fields), B, nloc, ny // P))
+    _call('nns_slab_transpose_unpack', suf, _p(recv), _ptr_array(fields), len(fields), B, nloc, ny, P, _stream())
+    return fields
+
+
 def spec_residual_ypass_(u, v, p, u_prev, v_prev, ru, rv, rd, dt, Ly, rho, nu, precise=True):
     suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev, ru, rv, rd)
     if suf != '_f32':
@@ -343,6 +458,18 @@ def basis_loss_fwd(coeff, basis, obs):
     ss = torch.zeros(1, dtype=torch.float64, device=coeff.device)
     check(_lib.lib().nns_basis_loss_fwd_f32(_p(coeff), _p(basis), _p(obs), _p(ss), T, K, C, P, _stream()), 'nns_basis_loss_fwd_f32')
     return ss
+
+
+def basis_loss_fused(coeff, basis, obs):
+    """ONE sweep over obs: returns (sumsq float64 device scalar, d(sumsq/2)/dcoeff, d(sumsq/2)/dbasis) -- the gradient without the
+    upstream / loss factor (nns_basis_loss_fused_f32)."""
+    _f32(coeff, basis, obs)
+    T, K, C = coeff.shape
+    P = basis.shape[2]
+    ss = torch.zeros(1, dtype=torch.float64, device=coeff.device)
+    gc, gb = torch.empty_like(coeff), torch.empty_like(basis)
+    check(_lib.lib().nns_basis_loss_fused_f32(_p(coeff), _p(basis), _p(obs), _p(ss), _p(gc), _p(gb), T, K, C, P, _stream()), 'nns_basis_loss_fused_f32')
+    return ss, gc, gb
 
 
 def basis_loss_bwd(coeff, basis, obs, scale):

@@ -1,134 +1,169 @@
-"""Slab decomposition of ONE periodic grid across the GPUs of a node.
+"""Slab decomposition of ONE grid across the GPUs of a node.
 
-Rank r owns rows [r*nx/P, (r+1)*nx/P) of every field ([B, nx/P, ny] local tensors).  One process per
-GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+Rank r owns rows [r*nx/P, (r+1)*nx/P) of every field ([B, nx/P, ny] local tensors).  One process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests and in the two-ranks-on-one-GPU
+rehearsal of the HIP path, see nns/_comm.py).
 
-  * FD residual: one nearest-neighbour exchange -- each rank sends its first / last row of u, v, p to
-    its ring neighbours (periodic wrap closes the ring; xGMI is point-to-point, so this uses exactly the
-    two direct links to the neighbours).  The three fields are packed into ONE message per direction.
-    The stencil kernel then runs on the halo-padded slab and the two halo rows of output are dropped.
-  * spectral residual: the y-pass (rows) is local.  The x-pass needs complete columns: ONE all-to-all
-    transposes u, v, p (packed) to column slabs [B, nx, ny/P], the x-pass kernel runs there, and ONE
-    all-to-all brings the three partial fields back -- 2 collectives per evaluation instead of 10 for a
-    library-style 2-D FFT per derivative.  An all-to-all uses all 7 xGMI links of a GPU concurrently.
+  * FD residual: one nearest-neighbour exchange -- each rank sends its first / last row of u, v, p to its ring neighbours
+    (periodic wrap closes the ring; xGMI is point-to-point, so this uses exactly the two direct links to the neighbours).
+    ONE kernel packs the three fields' edge rows into one message per direction; the stencil kernel reads the received
+    messages as rows -1 / nloc of the slab (no padded copies).  The interior rows, which touch no halo, are evaluated
+    while the exchange is in flight; the two edge rows follow once it has landed.
+  * spectral residual: the y-pass (rows) is local.  The x-pass needs complete columns: ONE kernel writes the all-to-all send
+    buffer [dest][u, v, p][B][nloc][ny/P], ONE all-to-all delivers [src][u, v, p][B][nloc][ny/P], the column pass READS THAT
+    LAYOUT IN PLACE (rows in blocks of nloc per source rank) and writes its three partials in the same layout, which is
+    the send buffer of the return all-to-all; ONE kernel scatters the returned blocks back into row slabs.  2 collectives
+    and 2 copy kernels per evaluation (a library-style 2-D FFT per derivative would need 10 transposes).
+  * both (the metric's unit, 5-point stencil): the halo exchange is started first and travels under the two transposes and the
+    column pass; the row pass then evaluates the stencil AND finishes the spectral residual in one launch
+    (nns_residual_both_rowpass_halo_f32) -- the fused form of the single-GPU headline.
   * SOR in the reference's lexicographic order does not shard (sequential fronts): replicas only.  The opt-in
-    RED-BLACK order does (SlabPressure below): one halo exchange per half-sweep and one all-reduce(max) per sweep.
+    RED-BLACK order does (SlabPressure below): one halo exchange per half-sweep and one all-reduce(max) per sweep, all
+    enqueued ahead with device-side stopping.
 
-The compute callables default to the HIP ops; the CPU tests inject oracle-based ones to check the
-decomposition logic (index ranges, packing, wrap-around) against the single-process result.
+The compute callables default to the HIP ops; the CPU tests inject oracle-based ones to check the decomposition logic
+(index ranges, message layouts, wrap-around) against the single-process result.
 """
 import math
 
 import torch
 import torch.distributed as dist
 
+from ._comm import Transport
+
 
 class HipCompute(object):
     """The product's compute back-end: hand-written HIP kernels through the C ABI (nns.ops)."""
 
-    def fd_residual(self, u, v, p, up, vp, dt, dx, dy, rho, nu, stencil):
+    def gather_lines(self, fields, msg, nouter, outer_stride, line_off, length, elem_stride=1):
         from . import ops
-        return ops.fd_residual(u, v, p, up, vp, dt, dx, dy, rho, nu, stencil)
+        return ops.slab_gather_lines(fields, msg, nouter, outer_stride, line_off, length, elem_stride)
 
-    def spec_xpass(self, u, v, p, Lx, rho, nu, precise):
+    def scatter_lines(self, msg, fields, nouter, outer_stride, line_off, length, elem_stride=1):
         from . import ops
-        return ops.spec_residual_xpass(u, v, p, Lx, rho, nu, precise)
+        return ops.slab_scatter_lines(msg, fields, nouter, outer_stride, line_off, length, elem_stride)
+
+    def transpose_pack(self, fields, send, P):
+        from . import ops
+        return ops.slab_transpose_pack(fields, send, P)
+
+    def transpose_unpack(self, recv, fields, P):
+        from . import ops
+        return ops.slab_transpose_unpack(recv, fields, P)
+
+    def fd_residual_halo(self, u, v, p, up, vp, top, bot, dt, dx, dy, rho, nu, stencil, rows, out):
+        from . import ops
+        return ops.fd_residual_halo(u, v, p, up, vp, top, bot, dt, dx, dy, rho, nu, stencil, rows, out)
+
+    def spec_xpass_seg(self, recv, send, B, nx, nyl, seg_rows, Lx, rho, nu, precise):
+        from . import ops
+        return ops.spec_residual_xpass_seg(recv, send, B, nx, nyl, seg_rows, Lx, rho, nu, precise)
 
     def spec_ypass(self, u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise):
         from . import ops
         return ops.spec_residual_ypass_(u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise)
 
+    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise):
+        from . import ops
+        return ops.residual_both_rowpass_halo(u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise)
+
 
 class SlabResidual(object):
     def __init__(self, nx, ny, dt, rho, nu, Lx=2 * math.pi, Ly=2 * math.pi, group=None, compute=None, precise=True):
-        self.group = group
-        self.P = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.tr = Transport(group)
+        self.group, self.P, self.rank = group, self.tr.P, self.tr.rank
         if nx % self.P or ny % self.P:
             raise ValueError("nx and ny must be divisible by the number of ranks (%d x %d over %d)" % (nx, ny, self.P))
         self.nx, self.ny, self.nloc, self.nyloc = nx, ny, nx // self.P, ny // self.P
+        if self.nloc < 3:
+            raise ValueError("need at least 3 rows per rank (%d over %d ranks)" % (nx, self.P))
         self.dt, self.rho, self.nu, self.Lx, self.Ly = dt, rho, nu, Lx, Ly
         self.dx, self.dy = Lx / nx, Ly / ny
         self.compute = compute if compute is not None else HipCompute()
         self.precise = precise
+        self._bufs = {}
+
+    def _buf(self, name, shape, like):
+        """Message buffers are allocated once per shape and reused (a collective in flight owns its buffers until wait())."""
+        key = (name, tuple(shape), like.dtype, like.device)
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return b
 
     # ------------------------------------------------------------------ FD: halo rows
-    def exchange_halo(self, fields):
-        """fields: list of [B, nloc, ny] tensors.  Returns them padded to [B, nloc+2, ny] with the periodic
-        neighbours' edge rows (one packed message per direction)."""
-        P, r = self.P, self.rank
-        up_rank, down_rank = (r - 1) % P, (r + 1) % P            # "up" owns the rows before ours
-        first = torch.stack([f[:, 0, :] for f in fields]).contiguous()       # goes to up_rank (their bottom halo)
-        last = torch.stack([f[:, -1, :] for f in fields]).contiguous()       # goes to down_rank (their top halo)
-        top_halo, bot_halo = torch.empty_like(last), torch.empty_like(first)
-        if P == 1:
-            top_halo.copy_(last), bot_halo.copy_(first)
-        else:
-            # With P == 2 both neighbours are the same peer and messages between a pair are matched in posting
-            # order: the peer sends (its first row -> our bottom halo, its last row -> our top halo), so the
-            # receives are posted in that order.
-            ops = [dist.P2POp(dist.isend, first, up_rank, self.group), dist.P2POp(dist.isend, last, down_rank, self.group),
-                   dist.P2POp(dist.irecv, bot_halo, down_rank, self.group), dist.P2POp(dist.irecv, top_halo, up_rank, self.group)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        out = []
-        for i, f in enumerate(fields):
-            out.append(torch.cat([top_halo[i][:, None, :], f, bot_halo[i][:, None, :]], dim=1).contiguous())
+    def start_halo(self, fields):
+        """fields: list of F [B, nloc, ny] row slabs.  Packs their first / last rows (ONE launch each) and starts the ring
+        exchange.  Returns (handle, top, bot): after handle.wait(), top / bot [F, B, ny] hold row -1 / row nloc of the slab
+        (the periodic neighbours' edge rows)."""
+        f0 = fields[0]
+        B, nloc, ny = f0.shape
+        F = len(fields)
+        first, last = self._buf('first', (F, B, ny), f0), self._buf('last', (F, B, ny), f0)
+        top, bot = self._buf('top', (F, B, ny), f0), self._buf('bot', (F, B, ny), f0)
+        c = self.compute
+        c.gather_lines(fields, first, B, nloc * ny, 0, ny)
+        c.gather_lines(fields, last, B, nloc * ny, (nloc - 1) * ny, ny)
+        return self.tr.ring_exchange(first, last, bot, top, wrap=True), top, bot
+
+    def fd(self, u, v, p, u_prev, v_prev, stencil=5, out=None):
+        h, top, bot = self.start_halo([u, v, p])
+        c, n = self.compute, self.nloc
+        out = out if out is not None else tuple(torch.empty_like(u) for _ in range(3))
+        args = (self.dt, self.dx, self.dy, self.rho, self.nu, stencil)
+        c.fd_residual_halo(u, v, p, u_prev, v_prev, top, bot, *args, (1, n - 1), out)       # interior rows: no halo needed yet
+        h.wait()
+        c.fd_residual_halo(u, v, p, u_prev, v_prev, top, bot, *args, (0, 1), out)
+        c.fd_residual_halo(u, v, p, u_prev, v_prev, top, bot, *args, (n - 1, n), out)
         return out
 
-    def fd(self, u, v, p, u_prev, v_prev, stencil=5):
-        pu, pv, pp = self.exchange_halo([u, v, p])
-        pad = lambda f: torch.cat([f[:, :1], f, f[:, -1:]], dim=1).contiguous()      # halo values of *_prev are never used
-        r = self.compute.fd_residual(pu, pv, pp, pad(u_prev), pad(v_prev), self.dt, self.dx, self.dy, self.rho, self.nu, stencil)
-        return tuple(t[:, 1:-1, :].contiguous() for t in r)
-
     # ------------------------------------------------------------------ spectral: all-to-all transpose
-    def _to_columns(self, fields):
-        """list of F [B, nloc, ny] row slabs -> [F, B, nx, nyloc] column slab (one all-to-all)."""
-        P = self.P
-        x = torch.stack(fields)                                                       # [F, B, nloc, ny]
-        F, B = x.shape[0], x.shape[1]
-        send = x.reshape(F, B, self.nloc, P, self.nyloc).permute(3, 0, 1, 2, 4).contiguous()   # [P(dest), F, B, nloc, nyloc]
-        recv = torch.empty_like(send)
-        if P == 1:
-            recv.copy_(send)
-        else:
-            dist.all_to_all_single(recv, send, group=self.group)
-        # recv[src] holds rows of rank src: concatenate along x
-        return recv.permute(1, 2, 0, 3, 4).reshape(F, B, self.nx, self.nyloc).contiguous()
-
-    def _to_rows(self, cols):
-        """[F, B, nx, nyloc] column slab -> list of F [B, nloc, ny] row slabs (one all-to-all)."""
-        P = self.P
-        F, B = cols.shape[0], cols.shape[1]
-        send = cols.reshape(F, B, P, self.nloc, self.nyloc).permute(2, 0, 1, 3, 4).contiguous()  # [P(dest), F, B, nloc, nyloc]
-        recv = torch.empty_like(send)
-        if P == 1:
-            recv.copy_(send)
-        else:
-            dist.all_to_all_single(recv, send, group=self.group)
-        x = recv.permute(1, 2, 3, 0, 4).reshape(F, B, self.nloc, self.ny)                        # columns of rank src side by side
-        return [x[i].contiguous() for i in range(F)]
+    def _xpass_partials(self, u, v, p):
+        """Row slabs u, v, p -> the column pass's three partials as row slabs (2 all-to-alls, 2 copy kernels)."""
+        B, nloc, ny = u.shape
+        P, nyl, c = self.P, self.nyloc, self.compute
+        shape = (P, 3, B, nloc, nyl)
+        send, recv = self._buf('a2a_s1', shape, u), self._buf('a2a_r1', shape, u)
+        c.transpose_pack([u, v, p], send, P)
+        self.tr.all_to_all(recv, send).wait()
+        back = self._buf('a2a_s2', shape, u)
+        c.spec_xpass_seg(recv, back, B, self.nx, nyl, nloc, self.Lx, self.rho, self.nu, self.precise)
+        got = self._buf('a2a_r2', shape, u)
+        self.tr.all_to_all(got, back).wait()
+        parts = [torch.empty_like(u) for _ in range(3)]
+        c.transpose_unpack(got, parts, P)
+        return parts
 
     def spectral(self, u, v, p, u_prev, v_prev):
-        cols = self._to_columns([u, v, p])
-        pu, pv, pd = self.compute.spec_xpass(cols[0], cols[1], cols[2], self.Lx, self.rho, self.nu, self.precise)
-        ru, rv, rd = self._to_rows(torch.stack([pu, pv, pd]))
+        ru, rv, rd = self._xpass_partials(u, v, p)
         return self.compute.spec_ypass(u, v, p, u_prev, v_prev, ru, rv, rd, self.dt, self.Ly, self.rho, self.nu, self.precise)
 
     def both(self, u, v, p, u_prev, v_prev, stencil=5):
-        return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev)
+        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- the halo exchange travels
+        under the transposes and the column pass, then ONE row pass does the stencil and finishes the spectral residual."""
+        if stencil != 5 or u.dtype not in getattr(self.compute, 'fused_dtypes', (torch.float32,)):
+            return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev)
+        h, top, bot = self.start_halo([u, v, p])
+        parts = self._xpass_partials(u, v, p)
+        h.wait()
+        return self.compute.both_rowpass_halo(u, v, p, u_prev, v_prev, top, bot, parts, self.dt, self.dx, self.Ly, self.rho, self.nu, self.precise)
 
 
 class HipSorCompute(object):
-    """Half-sweep back-end of SlabPressure: the HIP kernel nns_fd_sor_redblack_halfsweep_*."""
+    """Back-end of SlabPressure: the gated half-sweep kernel nns_fd_sor_redblack_halfsweep_gated_* and the halo-line pack /
+    scatter kernels."""
 
-    def halfsweep(self, p, C, err, gi0, colour, dx, dy, beta):
+    def gather_lines(self, fields, msg, nouter, outer_stride, line_off, length, elem_stride=1):
         from . import ops
-        return ops.fd_sor_redblack_halfsweep_(p, C, err, gi0, colour, dx, dy, beta)
+        return ops.slab_gather_lines(fields, msg, nouter, outer_stride, line_off, length, elem_stride)
 
-    def err_value(self, err):
-        return err          # the kernel max-accumulates the IEEE bit pattern of a non-negative value: it reads back as that value
+    def scatter_lines(self, msg, fields, nouter, outer_stride, line_off, length, elem_stride=1):
+        from . import ops
+        return ops.slab_scatter_lines(msg, fields, nouter, outer_stride, line_off, length, elem_stride)
+
+    def halfsweep_gated(self, p, C, err, prev_err, tol, gi0, colour, dx, dy, beta):
+        from . import ops
+        return ops.fd_sor_redblack_halfsweep_gated_(p, C, err, prev_err, tol, gi0, colour, dx, dy, beta)
 
 
 class SlabPressure(object):
@@ -138,18 +173,24 @@ class SlabPressure(object):
     Rank r owns interior-or-boundary rows [lo, hi) of the global grid; its working slab is those rows plus one halo row
     on each side that has a neighbour (the physical boundary rows 0 and nx-1 belong to the first / last rank and are
     never updated, exactly as in the single-process solver).  Per half-sweep: refresh the halo rows from the ring
-    neighbours (no wrap: the domain is not periodic), relax one colour; per sweep: all-reduce(max) of the local
-    max|p - pPrev|.  Same formula, relaxation factor, stopping rule and sweep cap as nns_fd_sor_redblack; the result is
-    bitwise the single-process red-black solve (a half-sweep only reads the other colour)."""
+    neighbours (no wrap: the domain is not periodic; one pack kernel, one message per direction, one scatter kernel),
+    relax one colour; per sweep: all-reduce(max) of the local max|p - pPrev|.  Same formula, relaxation factor, stopping
+    rule and sweep cap as nns_fd_sor_redblack; the result is bitwise the single-process red-black solve (a half-sweep
+    only reads the other colour).
 
-    def __init__(self, nx, ny, dx, dy, beta, tol=5e-6, group=None, compute=None, axis=0):
+    No host round trip per sweep: sweep s accumulates its error into slot s+1 of a device array, the all-reduce(max) of
+    that slot is enqueued on the stream, and the half-sweeps of sweep s+1 switch themselves off on the device unless
+    slot s+1 > tol (the reference's `while err > tol`, src/chorin_fd/simulate.py:190) -- the chain of the single-GPU
+    red-black solver with the collective in it.  The host reads the slots back once per `check_every` sweeps only to
+    stop enqueueing."""
+
+    def __init__(self, nx, ny, dx, dy, beta, tol=5e-6, group=None, compute=None, axis=0, check_every=16):
         """axis = 0: row slabs (the description above).  axis = 1: COLUMN slabs -- columns [lo, hi) of ny with halo
-        columns; "rows" below then reads "columns" (the halo lines are strided, so they are packed for the exchange)."""
+        columns; "rows" below then reads "columns" (the halo lines are strided; the pack kernel gathers them)."""
         assert axis in (0, 1)
         self.axis = axis
-        self.group = group
-        self.P = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.tr = Transport(group)
+        self.group, self.P, self.rank = group, self.tr.P, self.tr.rank
         n_split = nx if axis == 0 else ny
         if n_split < 3 * self.P:
             raise ValueError("need at least 3 lines per rank (%d over %d ranks)" % (n_split, self.P))
@@ -159,37 +200,47 @@ class SlabPressure(object):
         self.nx, self.ny, self.dx, self.dy, self.beta, self.tol = nx, ny, dx, dy, beta, tol
         self.has_up, self.has_down = self.rank > 0, self.rank < self.P - 1
         self.compute = compute if compute is not None else HipSorCompute()
+        self.check_every = max(1, int(check_every))
+        self._bufs = {}
 
     def local_rows(self, full):
         """This rank's rows (axis 0) or columns (axis 1) of a global [nx, ny] array."""
         return full[self.lo:self.hi] if self.axis == 0 else full[:, self.lo:self.hi]
 
-    def _line(self, a, i):
-        """Line i along the split axis (a view): row i, or column i."""
-        return a[i] if self.axis == 0 else a[:, i]
+    def _line_args(self, slab, i):
+        """(nouter, outer_stride, line_off, length, elem_stride) of line i (negative: from the end) along the split axis."""
+        n0, n1 = slab.shape
+        if self.axis == 0:
+            return 1, 0, (i % n0) * n1, n1, 1
+        return 1, 0, i % n1, n0, n1
+
+    def _msg(self, name, F, length, like):
+        key = (name, F, length, like.dtype, like.device)
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = torch.empty(F, 1, length, dtype=like.dtype, device=like.device)
+        return b
 
     def exchange_halo(self, *slabs):
-        """Refresh the halo rows of the given slabs ([nloc + has_up + has_down, ny] each) from the neighbours' edge rows:
-        ONE message per direction carrying all the fields (no wrap: the domain is not periodic)."""
+        """Refresh the halo lines of the given slabs ([nloc + has_up + has_down, ny] each, or the column-slab transpose of
+        that) from the neighbours' edge lines: ONE message per direction carrying all the fields (no wrap: the domain is
+        not periodic), packed and scattered by one kernel launch each."""
         if self.P == 1:
             return
-        up, down = self.has_up, self.has_down
-        reqs = []
-        if up:
-            first = torch.stack([self._line(a, 1) for a in slabs])
-            top = torch.empty_like(first)
-            reqs += [dist.isend(first, self.rank - 1, group=self.group), dist.irecv(top, self.rank - 1, group=self.group)]
-        if down:
-            last = torch.stack([self._line(a, -2) for a in slabs])
-            bot = torch.empty_like(last)
-            reqs += [dist.isend(last, self.rank + 1, group=self.group), dist.irecv(bot, self.rank + 1, group=self.group)]
-        for q in reqs:
-            q.wait()
-        for i, a in enumerate(slabs):
-            if up:
-                self._line(a, 0).copy_(top[i])
-            if down:
-                self._line(a, -1).copy_(bot[i])
+        c, F, slabs = self.compute, len(slabs), list(slabs)
+        length = self._line_args(slabs[0], 0)[3]
+        first = last = top = bot = None
+        if self.has_up:
+            first, top = self._msg('first', F, length, slabs[0]), self._msg('top', F, length, slabs[0])
+            c.gather_lines(slabs, first, *self._line_args(slabs[0], 1))
+        if self.has_down:
+            last, bot = self._msg('last', F, length, slabs[0]), self._msg('bot', F, length, slabs[0])
+            c.gather_lines(slabs, last, *self._line_args(slabs[0], -2))
+        self.tr.ring_exchange(first, last, bot, top, wrap=False).wait()
+        if self.has_up:
+            c.scatter_lines(top, slabs, *self._line_args(slabs[0], 0))
+        if self.has_down:
+            c.scatter_lines(bot, slabs, *self._line_args(slabs[0], -1))
 
     def to_slab(self, rows):
         """Owned rows [hi - lo, ny] -> working slab with (zeroed) halo rows."""
@@ -210,17 +261,28 @@ class SlabPressure(object):
     def solve_slab_(self, slab, cs, max_sweeps):
         """Red-black solve in place on the working slab (halo rows are refreshed here).  Returns (sweeps, last err)."""
         gi0 = self.lo - int(self.has_up)                      # global index of slab line 0: the colour of a point is (offset + i + j) % 2
-        err_buf = torch.zeros(1, dtype=slab.dtype, device=slab.device)
-        err, done = 1.0, 0
+        max_sweeps = int(max_sweeps)
+        # slots[0] = 1, the reference's initial err (:183); slots[s + 1] = max|p - pPrev| of sweep s over ALL ranks
+        slots = torch.zeros(max_sweeps + 1, dtype=slab.dtype, device=slab.device)
+        slots[0] = 1.0
+        # all-reduce(MAX) on the bit patterns: non-negative IEEE values order like integers, and the "switched off" marker of
+        # a skipped sweep (a NaN pattern, the largest positive integer) survives an integer maximum on every backend
+        bits = slots.view(torch.int32 if slab.dtype == torch.float32 else torch.int64)
+        vals, enq = None, 0
+        while enq < max_sweeps:
+            n = min(self.check_every, max_sweeps - enq)
+            for s in range(enq, enq + n):
+                for colour in (0, 1):
+                    self.exchange_halo(slab)
+                    self.compute.halfsweep_gated(slab, cs, slots[s + 1:s + 2], slots[s:s + 1], self.tol, gi0, colour, self.dx, self.dy, self.beta)
+                self.tr.all_reduce_(bits[s + 1:s + 2], dist.ReduceOp.MAX)
+            enq += n
+            vals = slots[:enq + 1].tolist()                   # the only host read: once per check_every sweeps
+            if any(not (e > self.tol) for e in vals[1:]):
+                break
+        err, done = 1.0, 0                                    # walk the slots as the reference's loop would (:190)
         while done < max_sweeps and err > self.tol:
-            err_buf.zero_()
-            for colour in (0, 1):
-                self.exchange_halo(slab)
-                self.compute.halfsweep(slab, cs, err_buf, gi0, colour, self.dx, self.dy, self.beta)
-            e = self.compute.err_value(err_buf).clone()
-            if self.P > 1:
-                dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)
-            err = float(e.item())
+            err = vals[done + 1]
             done += 1
         return done, err
 

@@ -335,7 +335,47 @@ def test_basis_loss_kernels_direct(shape, gpu_device):
     gc, gb = ops.basis_loss_bwd(*d, scale)
     assert rel_l2(gc.cpu().numpy(), np.einsum('tcp,kcp->tkc', g, b64)) < 2e-6
     assert rel_l2(gb.cpu().numpy(), np.einsum('tcp,tkc->kcp', g, c64)) < 2e-6
+    ss3, gc3, gb3 = ops.basis_loss_fused(*d)                               # ONE sweep: loss and the unscaled gradient
+    assert abs(float(ss3.item()) - np.sum((pred - o64)**2)) < 1e-6 * np.sum((pred - o64)**2)
+    assert rel_l2(gc3.cpu().numpy(), np.einsum('tcp,kcp->tkc', pred - o64, b64)) < 2e-6
+    assert rel_l2(gb3.cpu().numpy(), np.einsum('tcp,tkc->kcp', pred - o64, c64)) < 2e-6
     gc2, gb2 = ops.basis_expand_bwd(d[0], d[1], d[2])                      # upstream gradient = obs
     assert rel_l2(gc2.cpu().numpy(), np.einsum('tcp,kcp->tkc', o64, b64)) < 2e-6
     assert rel_l2(gb2.cpu().numpy(), np.einsum('tcp,tkc->kcp', o64, c64)) < 2e-6
     assert torch.allclose(ops.basis_expand(d[0], d[1]).cpu(), torch.as_tensor(pred, dtype=torch.float32), rtol=1e-4, atol=1e-4)
+
+
+def test_cfg5_shape_loss_and_gradients_are_sums_over_chunks(gpu_device):
+    """BASELINE config 5 at FULL shape -- T = nt * mb = 32 * 256 = 8192 time rows, K = 10, 3 channels, 256 x 256 pixels
+    (6.4 GB of observations) -- through size-independent properties: loss^2 and the gradients of the whole batch (ONE
+    fused sweep, nns_basis_loss_fused_f32) equal the sums over 8 chunks of 1024 rows, and chunk 0 is checked against the
+    float64 contraction on the host restricted to a pixel sample (the full contraction is 2e11 flops of NumPy)."""
+    from nns import ops
+    T, K, C, n = 8192, 10, 3, 256
+    P = n * n
+    g = torch.Generator(device='cuda').manual_seed(3)
+    coeff = torch.randn(T, K, C, device='cuda', generator=g) * 0.3
+    basis = torch.randn(K, C, P, device='cuda', generator=g)
+    obs = torch.randn(T, C, P, device='cuda', generator=g)
+    ss, gc, gb = ops.basis_loss_fused(coeff, basis, obs)
+    ss_fwd = ops.basis_loss_fwd(coeff, basis, obs)                      # the loss-only kernel agrees with the fused sweep
+    assert abs(float(ss.item()) - float(ss_fwd.item())) < 1e-9 * float(ss.item())
+    nchunk, rows = 8, T // 8
+    ss_sum, gb_sum = 0.0, torch.zeros_like(gb, dtype=torch.float64)
+    for c in range(nchunk):
+        sl = slice(c * rows, (c + 1) * rows)
+        s_c, gc_c, gb_c = ops.basis_loss_fused(coeff[sl].contiguous(), basis, obs[sl].contiguous())
+        ss_sum += float(s_c.item())
+        gb_sum += gb_c.double()
+        assert rel_l2(gc[sl].cpu().numpy(), gc_c.cpu().numpy()) < 2e-6          # a row's coefficient gradient only sees its own row
+        if c == 0:                                                      # float64 contraction on a sample of 4096 pixels
+            idx = torch.arange(0, P, P // 4096, device='cuda')[:4096]
+            c64, b64, o64 = coeff[sl].double(), basis[:, :, idx].double(), obs[sl][:, :, idx].double()
+            r = torch.einsum('tkc,kcp->tcp', c64, b64) - o64
+            ref_gb = torch.einsum('tcp,tkc->kcp', r, c64)
+            assert rel_l2(gb_c[:, :, idx].cpu().numpy(), ref_gb.cpu().numpy()) < 2e-6
+            s_small, gc_small, _ = ops.basis_loss_fused(coeff[sl].contiguous(), basis[:, :, idx].contiguous(), obs[sl][:, :, idx].contiguous())
+            assert abs(float(s_small.item()) - float((r * r).sum().item())) < 1e-6 * float(s_small.item())
+            assert rel_l2(gc_small.cpu().numpy(), torch.einsum('tcp,kcp->tkc', r, b64).cpu().numpy()) < 2e-6
+    assert abs(ss_sum - float(ss.item())) < 1e-9 * ss_sum
+    assert rel_l2(gb.cpu().numpy(), gb_sum.cpu().numpy()) < 2e-6

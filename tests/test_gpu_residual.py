@@ -161,6 +161,22 @@ def test_full_size_properties_1024_batch64(gpu_device):
         for a, b, c in zip(r64, r64b, r4):
             assert torch.equal(a, b)                                      # run-to-run bitwise
             assert torch.equal(a[:4], c) and torch.equal(a[60:], c)       # grid b of the batch == grid alone
+    # the exact launch configuration of the headline (bench.py): the FUSED two-launch form at 1024^2 x 64
+    bf, bs = eng.both(*big)
+    bf2, bs2 = eng.both(*big)
+    bf4, bs4 = eng.both(*fb)
+    sep_fd, sep_sp = eng.fd(*big, stencil=5), eng.spectral(*big)
+    for k in range(3):
+        assert torch.equal(bf[k], bf2[k]) and torch.equal(bs[k], bs2[k])                       # run-to-run bitwise
+        assert torch.equal(bf[k][:4], bf4[k]) and torch.equal(bf[k][60:], bf4[k])             # batch independence
+        assert torch.equal(bs[k][:4], bs4[k]) and torch.equal(bs[k][60:], bs4[k])
+        assert rel_l2(bf[k].cpu().numpy(), sep_fd[k].cpu().numpy()) < 1e-6                    # fused == separate kernels to rounding
+        assert rel_l2(bs[k].cpu().numpy(), sep_sp[k].cpu().numpy()) < 1e-6
+    from oracle import periodic as OP
+    f64 = [a.astype(np.float64) for a in inputs(4, n)]
+    ref_fd, ref_sp = OP.fd_residual(*f64, DT, L / n, L / n, RHO, NU, 5), OP.spectral_residual(*f64, DT, L, L, RHO, NU)
+    for k in range(3):
+        assert rel_l2(bf[k][60:].cpu().numpy(), ref_fd[k]) <= TOL and rel_l2(bs[k][60:].cpu().numpy(), ref_sp[k]) <= TOL
 
 
 def test_slab_residual_single_rank_uses_hip_backend(gpu_device):

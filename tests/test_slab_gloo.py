@@ -12,25 +12,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import periodic as OP
+from slab_oracle_compute import OracleChorin, OracleCompute, OracleSor
 
 NX, NY, B = 16, 24, 2
 DT, RHO, NU, LX, LY = 1e-2, 1.3, 0.05, 2 * np.pi, 3.0
-
-
-class OracleCompute(object):
-    """CPU stand-in for nns.slab.HipCompute (tests only)."""
-
-    def fd_residual(self, u, v, p, up, vp, dt, dx, dy, rho, nu, stencil):
-        r = OP.fd_residual(*[t.numpy() for t in (u, v, p, up, vp)], dt, dx, dy, rho, nu, stencil)
-        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in r)
-
-    def spec_xpass(self, u, v, p, Lx, rho, nu, precise):
-        r = OP.spectral_xpart(u.numpy(), v.numpy(), p.numpy(), Lx, rho, nu)
-        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in r)
-
-    def spec_ypass(self, u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise):
-        r = OP.spectral_ypart(*[t.numpy() for t in (u, v, p, up, vp, ru, rv, rd)], dt, Ly, rho, nu)
-        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in r)
 
 
 def fields():
@@ -47,23 +32,32 @@ def _worker(rank, world, port, out):
         nloc = NX // world
         loc = [torch.from_numpy(np.ascontiguousarray(a[:, rank * nloc:(rank + 1) * nloc])) for a in f]
         s = SlabResidual(NX, NY, DT, RHO, NU, LX, LY, compute=OracleCompute())
-        # halo rows really are the periodic neighbours' edge rows
-        padded = s.exchange_halo(loc[:3])
+        # halo messages really are the periodic neighbours' edge rows
+        h, top, bot = s.start_halo(loc[:3])
+        h.wait()
         for k in range(3):
-            np.testing.assert_array_equal(padded[k][:, 0].numpy(), f[k][:, (rank * nloc - 1) % NX])
-            np.testing.assert_array_equal(padded[k][:, -1].numpy(), f[k][:, ((rank + 1) * nloc) % NX])
-        # transposes are exact inverses and put the right data in the right place
-        cols = s._to_columns(loc[:3])
+            np.testing.assert_array_equal(top[k].numpy(), f[k][:, (rank * nloc - 1) % NX])
+            np.testing.assert_array_equal(bot[k].numpy(), f[k][:, ((rank + 1) * nloc) % NX])
+        # the all-to-all delivers, from every source rank, its rows of this rank's column block; the return trip inverts it
         nyl = NY // world
+        send, recv = torch.empty(world, 3, B, nloc, nyl, dtype=torch.float64), torch.empty(world, 3, B, nloc, nyl, dtype=torch.float64)
+        s.compute.transpose_pack(loc[:3], send, world)
+        s.tr.all_to_all(recv, send).wait()
+        for src in range(world):
+            for k in range(3):
+                np.testing.assert_array_equal(recv[src, k].numpy(), f[k][:, src * nloc:(src + 1) * nloc, rank * nyl:(rank + 1) * nyl])
+        back = torch.empty_like(recv)
+        s.tr.all_to_all(back, recv).wait()
+        got = [torch.empty_like(t) for t in loc[:3]]
+        s.compute.transpose_unpack(back, got, world)
         for k in range(3):
-            np.testing.assert_array_equal(cols[k].numpy(), f[k][:, :, rank * nyl:(rank + 1) * nyl])
-        back = s._to_rows(cols)
-        for k in range(3):
-            np.testing.assert_array_equal(back[k].numpy(), loc[k].numpy())
+            np.testing.assert_array_equal(got[k].numpy(), loc[k].numpy())
         res = {}
         for st in (5, 9):
             res['fd%d' % st] = [t.numpy() for t in s.fd(*loc, stencil=st)]
         res['spec'] = [t.numpy() for t in s.spectral(*loc)]
+        both = s.both(*loc)                                     # the fused form: halo under the transposes, one row pass
+        res['bfd'], res['bspec'] = [t.numpy() for t in both[0]], [t.numpy() for t in both[1]]
         np.savez(os.path.join(out, 'r%d.npz' % rank), **{k + '_%d' % i: a for k, v in res.items() for i, a in enumerate(v)})
     finally:
         dist.destroy_process_group()
@@ -82,6 +76,7 @@ def test_slab_decomposition_matches_single_process(world, tmp_path):
     hx, hy = LX / NX, LY / NY
     ref = {'fd5': OP.fd_residual(*f, DT, hx, hy, RHO, NU, 5), 'fd9': OP.fd_residual(*f, DT, hx, hy, RHO, NU, 9),
            'spec': OP.spectral_residual(*f, DT, LX, LY, RHO, NU)}
+    ref['bfd'], ref['bspec'] = ref['fd5'], ref['spec']
     parts = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
     for key, r in ref.items():
         for i in range(3):
@@ -108,27 +103,6 @@ def test_world_size_one_degenerates_to_local(tmp_path):
 PNX, PNY, PBETA, PCAP = 27, 14, 1.5, 60
 
 
-class OracleSor(object):
-    """CPU stand-in for HipSorCompute (tests only): one colour of oracle.chorin_fd.sor_sweep_redblack on the slab."""
-
-    def halfsweep(self, p, C, err, gi0, colour, dx, dy, beta):
-        a = p.numpy()
-        nxl, ny = a.shape
-        I, J = np.meshgrid(np.arange(1, nxl - 1), np.arange(1, ny - 1), indexing='ij')
-        m = ((I + gi0 + J) % 2) == colour
-        i, j = I[m], J[m]
-        c = C.numpy()
-        new = (beta * (dy**2 * a[i + 1, j] + dy**2 * a[i - 1, j] + dx**2 * a[i, j + 1] + dx**2 * a[i, j - 1] - c[i, j]) / (2 * dx**2 + 2 * dy**2)
-               + (1 - beta) * a[i, j])
-        if new.size:
-            err[0] = max(float(err[0]), float(np.max(np.abs(new - a[i, j]))))
-        a[i, j] = new
-        return err
-
-    def err_value(self, err):
-        return err
-
-
 def pressure_problem():
     rng = np.random.default_rng(5)
     return 0.01 * rng.standard_normal((PNX, PNY)), 0.1 * rng.standard_normal((PNX, PNY))
@@ -145,6 +119,12 @@ def _pworker(rank, world, port, out):
         done, err = s.solve_(pl, torch.from_numpy(np.ascontiguousarray(s.local_rows(C))), PCAP)
         np.save(os.path.join(out, 'p%d.npy' % rank), pl.numpy())
         np.save(os.path.join(out, 'i%d.npy' % rank), np.array([done, err, s.lo, s.hi]))
+        # early stop in the middle of an enqueued chunk (check_every = 5): the sweeps after the stopping one switch themselves off
+        s2 = SlabPressure(PNX, PNY, 1.0 / PNX, 1.0 / PNY, PBETA, tol=0.5, compute=OracleSor(), check_every=5)
+        pl2 = torch.from_numpy(np.array(s2.local_rows(pressure_problem()[0])))          # a fresh copy: with one rank the first solve ran in place on p0
+        done2, err2 = s2.solve_(pl2, torch.from_numpy(np.ascontiguousarray(s2.local_rows(C))), PCAP)
+        np.save(os.path.join(out, 'q%d.npy' % rank), pl2.numpy())
+        np.save(os.path.join(out, 'j%d.npy' % rank), np.array([done2, err2]))
     finally:
         dist.destroy_process_group()
 
@@ -165,41 +145,20 @@ def test_slab_pressure_redblack(world, tmp_path):
     assert got.shape == ref.shape and np.array_equal(got, ref)
     assert all(int(i[0]) == sweeps and i[1] == err for i in info)
     assert [int(i[2]) for i in info] == [sum(len(x) for x in np.array_split(np.arange(PNX), world)[:r]) for r in range(world)]
+    ref = p0.copy(); err, sweeps, prev = 1.0, 0, p0.copy()
+    while err > 0.5 and sweeps < PCAP:
+        O.sor_sweep_redblack(ref, C, 1.0 / PNX, 1.0 / PNY, PBETA)
+        err = np.max(np.abs(ref - prev)); prev = ref.copy(); sweeps += 1
+    assert 0 < sweeps < PCAP and sweeps % 5 != 0                           # the stop falls inside a chunk of 5 enqueued sweeps
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), 'q%d.npy' % r)) for r in range(world)])
+    assert np.array_equal(got, ref)
+    assert all(int(j[0]) == sweeps and j[1] == err for j in (np.load(os.path.join(str(tmp_path), 'j%d.npy' % r)) for r in range(world)))
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # the whole chorin_fd cavity step sharded by rows (nns.slab.SlabChorinFD): bitwise the single-process oracle run
 # ------------------------------------------------------------------------------------------------------------------
 CNX, CNY, CNT, CNIT = 22, 17, 6, 30
-
-
-class OracleChorin(OracleSor):
-    """CPU stand-in for HipChorinCompute (tests only): the oracle's operators applied to the slab arrays."""
-
-    def predictor(self, un, vn, un1, vn1, dt, dx, dy, nu, corrected):
-        from oracle import chorin_fd as O
-        f = O.explicit_predictor_corrected if corrected else O.explicit_predictor
-        ui, vi = f(un.numpy(), vn.numpy(), un1.numpy(), vn1.numpy(), dt, dx, dy, nu)
-        return torch.from_numpy(ui), torch.from_numpy(vi)
-
-    def predictor_adi(self, un, vn, un1, vn1, dt, dx, dy, nu):
-        from oracle import chorin_fd as O
-        ui, vi = O.semi_implicit_predictor(un.numpy(), vn.numpy(), un1.numpy(), vn1.numpy(), dt, dx, dy, nu, column_slab=True)
-        return torch.from_numpy(ui), torch.from_numpy(vi)
-
-    def bc_apply_(self, A, bcs):
-        from oracle.boundary import apply_bc_list
-        apply_bc_list(A.numpy(), bcs)
-        return A
-
-    def rhs(self, ui, vi, dt, dx, dy, rho):
-        from oracle import chorin_fd as O
-        return torch.from_numpy(O.pressure_rhs(ui.numpy(), vi.numpy(), dt, dx, dy, rho))
-
-    def correction(self, ui, vi, p, dt, dx, dy):
-        from oracle import chorin_fd as O
-        u, v = O.correction(ui.numpy(), vi.numpy(), p.numpy(), dt, dx, dy)
-        return torch.from_numpy(u), torch.from_numpy(v)
 
 
 def cavity_problem():

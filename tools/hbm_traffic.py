@@ -16,6 +16,13 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             if s and r['Counter_Name'] == c:
                 acc[s].append(float(r['Counter_Value']))
     val[c] = {k: sum(v) / len(v) for k, v in acc.items()}
+import subprocess
 out = {k: (2 * val['FETCH_SIZE'][k] + val['WRITE_SIZE'][k]) * 1024 for k in val['FETCH_SIZE']}
+try:
+    commit = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = ''
+out['_source'] = dict(tag=tag, commit_at_summary=commit, passes='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass) over bench.py --steps 3; '
+                      'bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, averaged over launches')
 json.dump(out, open(os.path.join(root, 'profiles', 'hbm_traffic.json'), 'w'), indent=1)
 print(out)
