@@ -49,9 +49,27 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
     C2<TF> z[16];
     // ---- pressure: Z2 = FFT(p); keep only its contribution to b, already scaled, in float
+#ifndef NNS_EXP_P
+#define NNS_EXP_P 0        // timing experiments only (wrong results): 1 = skip FFT(p), 2 = FFT(p) in float32
+#endif
+#if NNS_EXP_P == 2
+    {
+        C2<float> zf[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { zf[m].x = pf[m]; zf[m].y = 0.f; }
+        fft_line<float, N, false, 0>(zf, tabI, tabI2, xbI, tid, hook);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { z[m].x = (TF)zf[m].x; z[m].y = (TF)zf[m].y; }
+    }
+#elif NNS_EXP_P == 1
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
+    static_for<0, FftPasses<N>::value>([&](auto sc) { hook(std::integral_constant<int, decltype(sc)::value>{}); });
+#else
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
     fft_line<TF, N, false, 0>(z, tabF, tabF2, xbF, tid, hook);
+#endif
     // The per-element wavenumber factors depend only on the lane id: left alone, instruction selection
     // computes all 16 (fp64) during the butterflies above and spills them.  Tie the lane id to the
     // transform's output so they are computed here, where they are used.
@@ -296,6 +314,163 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------
+// FD 5-point + spectral row pass, MARCHING (nns_residual_both_f32).  In spec_ypass_kernel<.., FUSE_FD = true> the eight
+// waves of a workgroup take eight adjacent rows and fetch the stencil's rows i-1 / i+1 again after the spectral epilogue:
+// each workgroup iteration streams 352 KB, an XCD's 4 MB L2 turns over in a third of an iteration, so two thirds of those
+// re-reads go back to the fabric (measured 4.95 GB per launch against 3.76 GB algorithmic, r01 PMC passes).  Here every line
+// (one wave at N = 1024) walks DOWN a band of R consecutive rows of one grid instead: row i+1 is the line it has already
+// prefetched for its next transform, row i-1 of u and v is its previous line, and p's j-1 / j+1 come from lane rotates like
+// u's and v's -- the stencil issues no loads except p[i-1].  Row i-1 of u, v rides through the float64 forward transforms
+// in registers and is PARKED in LDS for the rest of the iteration: the float32 inverse transforms use only the lower half of
+// the line's exchange image, the upper half (8.5 N bytes >= the 8 N needed) is free exactly when the register file is full
+// (inverse transforms, epilogue loads).  Extra traffic: two rows of u, v, p per band (2 / R of three streams) + 4 B/pt.
+// ------------------------------------------------------------------------------------------
+template <int N, typename TF>
+struct MarchLds {
+    using L = SpecLds<N, TF>;
+    static constexpr int PARK_OFF = (L::SLOTS * (int)sizeof(C2<float>) + 15) / 16 * 16;      // above the float32 exchange image
+    static constexpr int NEED = PARK_OFF + 2 * N * 4;
+    static constexpr int LINE_BYTES = ((NEED > L::LINE_BYTES ? NEED : L::LINE_BYTES) + 127) / 128 * 128;
+    static constexpr int TOTAL = L::TABF_BYTES + L::TABI_BYTES + L::LINES * LINE_BYTES;
+};
+template <int N, typename TF>
+__global__ __launch_bounds__(kSpecThreads) void both_rowpass_march_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                           const float* __restrict__ p, const float* __restrict__ up,
+                                                                           const float* __restrict__ vp, float* __restrict__ ru,
+                                                                           float* __restrict__ rv, float* __restrict__ rd,
+                                                                           float* __restrict__ fu, float* __restrict__ fv, float* __restrict__ fd,
+                                                                           int nx, FdK fk, int R, int bpg, long nbands, SpecK k, HaloK hk) {
+    using L = SpecLds<N, TF>;
+    using M = MarchLds<N, TF>;
+    constexpr int TPF = L::TPF;
+    constexpr bool NT = NNS_YPASS_NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, TF>(smem, tabF, tabI, lines);
+    const long total_lines = (long)gridDim.x * L::LINES;
+    const long rounds = (nbands + total_lines - 1) / total_lines;            // the same trip count for every line (wave-synchronous exchanges)
+    for (long rnd = 0; rnd < rounds; ++rnd) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        int line = wave * L::FPW + sub;
+        // one line per wave (N = 1024): the band, its grid and every row address are wave-uniform -- keep them in scalar registers
+        if constexpr (L::FPW == 1) line = __builtin_amdgcn_readfirstlane(line);
+        unsigned char* xb = lines + (size_t)line * M::LINE_BYTES;
+        float* park = reinterpret_cast<float*>(xb + M::PARK_OFF) + tid;           // [u | v][N], element tid + TPF m at park[field * N + TPF m]
+        const long band_raw = rnd * total_lines + (long)blockIdx.x * L::LINES + line;
+        const bool band_ok = band_raw < nbands;
+        const long band = band_ok ? band_raw : nbands - 1;
+        const long gi = band / bpg;
+        const int ii0 = (int)(band % bpg) * R;
+        const size_t gbase = (size_t)gi * nx * N;                               // first element of this line's grid
+        // row ii of the grid (ii in [-1, nx]): -1 / nx are the halo messages of a row slab, or wrap around inside the grid
+        auto row_ptr = [&](const float* f, int field, int ii) -> const float* {
+            if (ii < 0) return hk.top ? hk.top + field * hk.fstride + (size_t)gi * N : f + gbase + (size_t)(nx - 1) * N;
+            if (ii >= nx) return hk.bot ? hk.bot + field * hk.fstride + (size_t)gi * N : f + gbase;
+            return f + gbase + (size_t)ii * N;
+        };
+        float um[16], vm[16], nu[16], nv[16], np[16];
+        {   // band prologue: row ii0 - 1 (u, v) and row ii0
+            const float* q0 = row_ptr(u, 0, ii0 - 1) + tid; const float* q1 = row_ptr(v, 1, ii0 - 1) + tid;
+            const size_t c0 = gbase + (size_t)ii0 * N + tid;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                um[m] = q0[TPF * m]; vm[m] = q1[TPF * m];
+                nu[m] = u[c0 + TPF * m]; nv[m] = v[c0 + TPF * m]; np[m] = p[c0 + TPF * m];
+            }
+        }
+        for (int s = 0; s < R; ++s) {
+            int tidv = tid;
+            asm volatile("" : "+v"(tidv));                                         // see spec_ypass_kernel: keeps lane-invariant factors from being hoisted
+            const int ii_raw = ii0 + s;
+            const bool valid = band_ok && ii_raw < nx;
+            const int ii = ii_raw < nx ? ii_raw : nx - 1;
+            const size_t base = gbase + (size_t)ii * N + tidv;
+            float uf[16], vf[16], pf[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { uf[m] = nu[m]; vf[m] = nv[m]; pf[m] = np[m]; }
+            const float* nq0 = row_ptr(u, 0, ii + 1) + tidv; const float* nq1 = row_ptr(v, 1, ii + 1) + tidv; const float* nq2 = row_ptr(p, 2, ii + 1) + tidv;
+            auto hook = [&](auto sc) {
+                if constexpr (decltype(sc)::value == 2 * FftPasses<N>::value - 1) {
+                    // after the last forward pass: the float64 image is dead -- park row i-1 above the float32 image, and request
+                    // row i + 1 (the stencil's lower neighbour and the next transform's input) into the registers just freed
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) { park[TPF * m] = um[m]; park[N + TPF * m] = vm[m]; }
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) { nu[m] = nq0[TPF * m]; nv[m] = nq1[TPF * m]; np[m] = nq2[TPF * m]; }
+                }
+            };
+            C2<float> a[16], b[16];
+            asm volatile("; MARCH-PHASE transforms");
+            deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k, hook);
+            asm volatile("; MARCH-PHASE epilogue");
+            float pmr[16];                                                           // p[i-1]: the one neighbour row read again (4 B/pt)
+            float tu[16], tv[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float pu[8], pv[8], pd[8], qu[8], qv[8];
+                if (h == 1) {                                                        // requested once half of a, b is dead
+                    const float* q2 = row_ptr(p, 2, ii - 1) + tidv;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) pmr[m] = q2[TPF * m];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const size_t c = base + TPF * (8 * h + i);
+                    pu[i] = ld_stream<NT>(ru + c); pv[i] = ld_stream<NT>(rv + c); pd[i] = ld_stream<NT>(rd + c);
+                    qu[i] = ld_stream<NT>(up + c); qv[i] = ld_stream<NT>(vp + c);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = 8 * h + i;
+                    tu[m] = __fmul_rn(uf[m] - qu[i], k.inv_dt); tv[m] = __fmul_rn(vf[m] - qv[i], k.inv_dt);
+                }
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = 8 * h + i;
+                        const size_t c = base + TPF * m;
+                        st_stream<NT>(ru + c, __fadd_rn(__fmaf_rn(vf[m], a[m].x, __fadd_rn(tu[m], pu[i])), b[m].x));
+                        st_stream<NT>(rv + c, __fadd_rn(__fmaf_rn(vf[m], a[m].y, __fadd_rn(tv[m], pv[i])), b[m].y));
+                        st_stream<NT>(rd + c, pd[i] + a[m].y);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the stencil: rows i-1 (back from LDS), i, i+1 (landed under the inverse transforms) are all on chip
+            asm volatile("; MARCH-PHASE stencil");
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { um[m] = park[TPF * m]; vm[m] = park[N + TPF * m]; }
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                const size_t c = base + TPF * m;
+                const float ucc = uf[m], vcc = vf[m];
+                const float ul = left_of<m, TPF>(uf, tidv), ur = right_of<m, TPF>(uf, tidv);
+                const float vl = left_of<m, TPF>(vf, tidv), vr = right_of<m, TPF>(vf, tidv);
+                const float pl = left_of<m, TPF>(pf, tidv), pr = right_of<m, TPF>(pf, tidv);
+                const float ux = (nu[m] - um[m]) * fk.inv_2dx, uy = (ur - ul) * fk.inv_2dy;
+                const float vx = (nv[m] - vm[m]) * fk.inv_2dx, vy = (vr - vl) * fk.inv_2dy;
+                const float px = (np[m] - pmr[m]) * fk.inv_2dx, py = (pr - pl) * fk.inv_2dy;
+                const double lu = ((double)nu[m] - 2.0 * ucc + (double)um[m]) * fk.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * fk.inv_dy2;
+                const double lv = ((double)nv[m] - 2.0 * vcc + (double)vm[m]) * fk.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * fk.inv_dy2;
+                if (valid) {
+                    st_stream<NT>(fu + c, tu[m] + ucc * ux + vcc * uy + px * fk.inv_rho - fk.nu * (float)lu);
+                    st_stream<NT>(fv + c, tv[m] + ucc * vx + vcc * vy + py * fk.inv_rho - fk.nu * (float)lv);
+                    st_stream<NT>(fd + c, ux + vy);
+                }
+            });
+            asm volatile("; MARCH-PHASE carry");
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { um[m] = uf[m]; vm[m] = vf[m]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // x-pass: columns.  A workgroup owns LINES adjacent columns of one grid; the tile is staged
 // through LDS so that global accesses are row pieces of LINES*4 bytes.
 // ------------------------------------------------------------------------------------------
@@ -485,6 +660,39 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
     return check_launch("spec_residual_ypass");
 }
 
+#ifndef NNS_ROWPASS_MARCH
+#define NNS_ROWPASS_MARCH 0       // 1: marching fused row pass (both_rowpass_march_kernel), 0: spec_ypass_kernel<FUSE_FD>
+#endif
+template <int N, typename TF>
+int launch_rowpass_march(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
+                         float* fu, float* fv, float* fd, int batch, int nx, const SpecK& k, const FdK& fk, const HaloK& hk, hipStream_t s) {
+    using L = SpecLds<N, TF>;
+    using M = MarchLds<N, TF>;
+    auto kern = both_rowpass_march_kernel<N, TF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M::TOTAL);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "both rowpass: hipFuncSetAttribute(%d B): %s", M::TOTAL, hipGetErrorString(e));
+        attr_set = true;
+    }
+    // band height: as tall as keeps every line of the launch busy (halo overhead 2 / R on three of the streams), at most 64 rows
+    const long gmax = spec_grid_cap();
+    const long nrows = (long)batch * nx;
+    long grid = (nrows / 4 + L::LINES - 1) / L::LINES;                          // never more lines than bands of >= 4 rows
+    if (grid > gmax) grid = gmax;
+    if (grid < 1) grid = 1;
+    const long total_lines = grid * L::LINES;
+    long R = nrows / total_lines;
+    R = R < 4 ? 4 : (R > 64 ? 64 : R);
+    static const long r_env = [] { const char* e = getenv("NNS_MARCH_R"); return e ? atol(e) : 0L; }();      // tuning override
+    if (r_env > 0) R = r_env;
+    if (R > nx) R = nx;
+    const int bpg = (int)((nx + R - 1) / R);
+    const long nbands = (long)batch * bpg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kSpecThreads), M::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, (int)R, bpg, nbands, k, hk);
+    return check_launch("residual_both_rowpass");
+}
+
 int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
           double Lx, double rho, double nu, int precise, hipStream_t s, int seg_rows = 0, long seg_stride = 0) {
     if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
@@ -540,12 +748,17 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     const double ks = 2.0 * M_PI / Ly, dx = slab ? Lx : Lx / nx, dy = Ly / ny;          // a row slab passes the grid spacing itself in Lx
     const SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy)};
-    const long nrows = (long)batch * nx;
     const HaloK hk{halo_top, halo_bot, (long)batch * ny};
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
+#if NNS_ROWPASS_MARCH
+        return precise ? launch_rowpass_march<N, double>(u, v, p, up, vp, ru, rv, rd, fu, fv, fd, batch, nx, k, fk, hk, s)
+                       : launch_rowpass_march<N, float>(u, v, p, up, vp, ru, rv, rd, fu, fv, fd, batch, nx, k, fk, hk, s);
+#else
+        const long nrows = (long)batch * nx;
         return precise ? launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk)
                        : launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk);
+#endif
     });
 }
 

@@ -346,11 +346,11 @@ def test_backward_adjoint_identity_full_size(gpu_device, backend):
 
 
 def same_to_an_ulp(a, b):
-    """Equal except for a minority of elements one or two ulps of the largest value apart (two instantiations of the same
-    source may contract FMAs differently)."""
+    """Equal except for elements one or two ulps of the largest value apart (two instantiations of the same source may
+    contract FMAs differently): max difference <= 2 ulp of the largest value, rel-L2 <= 1e-7."""
     diff = (a - b).abs()
     ulp = float(b.abs().max()) * 2.0 ** -23
-    assert float(diff.max()) <= 2 * ulp and int((diff > 0).sum()) <= a.numel() // 10
+    assert float(diff.max()) <= 2 * ulp and float(diff.double().norm() / b.double().norm()) <= 1e-7
 
 
 @pytest.mark.parametrize('nx,ny,batch', [(64, 1024, 3), (256, 1024, 2), (1024, 1024, 4), (128, 64, 5), (64, 128, 3), (512, 256, 2), (256, 512, 2)])
