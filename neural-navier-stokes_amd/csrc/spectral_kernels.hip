@@ -33,97 +33,6 @@ using namespace nns::spec;
 
 namespace {
 
-// The shared core: from the line's u, v, p (element tid + TPF*m in slot m) produce
-//   a = (f_u', f_v')  and  b = (L_u, L_v)  with the pressure-gradient term added to the real part
-//   (P_IN_REAL, x-pass) or the imaginary part (y-pass) of b.
-// `hook` is called at the 4 * FftPasses<N> pass boundaries (slot numbers 0 .. 4 P - 1), see fft_line.
-template <int N, typename TF, bool P_IN_REAL, typename Hook = NoHook>
-__device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&vf)[16], const float (&pf)[16],
-                                           C2<float> (&a)[16], C2<float> (&b)[16],
-                                           const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid,
-                                           const SpecK& k, Hook&& hook = Hook{}) {
-    constexpr int P = FftPasses<N>::value;
-    const C2<TF>* tabF2 = tabF + N / 2;
-    const C2<float>* tabI2 = tabI + N / 2;
-    C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);
-    C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
-    C2<TF> z[16];
-    // ---- pressure: Z2 = FFT(p); keep only its contribution to b, already scaled, in float
-#ifndef NNS_EXP_P
-#define NNS_EXP_P 0        // timing experiments only (wrong results): 1 = skip FFT(p), 2 = FFT(p) in float32
-#endif
-#if NNS_EXP_P == 2
-    {
-        C2<float> zf[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) { zf[m].x = pf[m]; zf[m].y = 0.f; }
-        fft_line<float, N, false, 0>(zf, tabI, tabI2, xbI, tid, hook);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) { z[m].x = (TF)zf[m].x; z[m].y = (TF)zf[m].y; }
-    }
-#elif NNS_EXP_P == 1
-#pragma unroll
-    for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
-    static_for<0, FftPasses<N>::value>([&](auto sc) { hook(std::integral_constant<int, decltype(sc)::value>{}); });
-#else
-#pragma unroll
-    for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
-    fft_line<TF, N, false, 0>(z, tabF, tabF2, xbF, tid, hook);
-#endif
-    // The per-element wavenumber factors depend only on the lane id: left alone, instruction selection
-    // computes all 16 (fp64) during the butterflies above and spills them.  Tie the lane id to the
-    // transform's output so they are computed here, where they are used.
-    int te = tid;
-    asm volatile("" : "+v"(te), "+v"(z[0].x));
-    static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        int ko, ke;
-        wavenumber<N, m>(te, ko, ke);
-        const TF s = (TF)((double)ko * k.cs);
-        if constexpr (P_IN_REAL) { b[m].x = (float)(-s * z[m].y); b[m].y = (float)(s * z[m].x); }   // (i k/rho) Z2
-        else { b[m].x = (float)(-s * z[m].x); b[m].y = (float)(-s * z[m].y); }                       // i (i k/rho) Z2
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- velocity: Z1 = FFT(u + i v)
-#pragma unroll
-    for (int m = 0; m < 16; ++m) { z[m].x = (TF)uf[m]; z[m].y = (TF)vf[m]; }
-    fft_line<TF, N, false, P>(z, tabF, tabF2, xbF, tid, hook);
-    te = tid;
-    asm volatile("" : "+v"(te), "+v"(z[0].x));
-    static_for<0, 16>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        int ko, ke;
-        wavenumber<N, m>(te, ko, ke);
-        const TF k1 = (TF)((double)ko * k.c1);
-        const TF k2 = (TF)((double)(ke * ke) * k.c2);                         // ke^2 <= 2^18: exact
-        a[m].x = (float)(-k1 * z[m].y); a[m].y = (float)(k1 * z[m].x);        // i k Z1
-        b[m].x += (float)(k2 * z[m].x); b[m].y += (float)(k2 * z[m].y);       // nu k^2 Z1
-    });
-    // ---- inverse transforms in float32
-    __builtin_amdgcn_sched_barrier(0);
-    fft_line<float, N, true, 2 * P>(a, tabI, tabI2, xbI, tid, hook);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_line<float, N, true, 3 * P>(b, tabI, tabI2, xbI, tid, hook);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// Constants of the fused FD 5-point residual (nns_residual_both_f32): the y-pass owns whole rows, so the stencil's j-1 /
-// j+1 neighbours of u and v are already in its registers (adjacent lane, or the adjacent 64-column slot at the wave's
-// ends) and the rows i-1 / i+1 are re-read from L2 -- the stencil back-end then costs no second pass over the inputs.
-struct FdK { float inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2; };
-// Row slabs of a grid sharded over ranks (nns/slab.py): the stencil's row above local row 0 / below local row nx-1 comes from
-// the neighbour rank's edge rows, delivered as [u, v, p][grid][N] messages (top / bot; stride = grids * N).  NULL: the
-// rows wrap around inside the local grid (single process).
-struct HaloK { const float* top; const float* bot; long fstride; };
-#ifndef NNS_YPASS_NT
-#define NNS_YPASS_NT 1            // non-temporal hints on the fused row pass's write-once outputs and read-once streams (0.84 -> 0.78 ms)
-#endif
-#ifndef NNS_YPASS_NT_PLAIN
-#define NNS_YPASS_NT_PLAIN 0      // the same hints in the plain (not fused) row pass
-#endif
-template <bool NT> __device__ __forceinline__ float ld_stream(const float* q) { if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; }
-template <bool NT> __device__ __forceinline__ void st_stream(float* q, float x) { if constexpr (NT) __builtin_nontemporal_store(x, q); else *q = x; }
-
 __device__ __forceinline__ float wave_ror1(float x) {          // lane i <- lane i-1, lane 0 <- lane 63
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
 }
@@ -158,6 +67,112 @@ __device__ __forceinline__ float right_of(const float (&x)[16], int tid) {
         return tid == TPF - 1 ? w : r;
     }
 }
+
+
+// The shared core: from the line's u, v, p (element tid + TPF*m in slot m) produce
+//   a = (f_u', f_v')  and  b = (L_u, L_v)  with the pressure-gradient term added to the real part
+//   (P_IN_REAL, x-pass) or the imaginary part (y-pass) of b.
+// `hook` is called at the 4 * FftPasses<N> pass boundaries (slot numbers 0 .. 4 P - 1), see fft_line.
+template <int N, typename TF, bool P_IN_REAL, typename Hook = NoHook>
+__device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&vf)[16], const float (&pf)[16],
+                                           C2<float> (&a)[16], C2<float> (&b)[16],
+                                           const C2<TF>* tabF, const C2<float>* tabI, unsigned char* xb_raw, int tid,
+                                           const SpecK& k, Hook&& hook = Hook{}) {
+    const float* ctab = reinterpret_cast<const float*>(tabI + N / 2 + Pass2<N>::ENTRIES);      // behind the float32 tables (spec_setup)
+    constexpr int P = FftPasses<N>::value;
+    const C2<TF>* tabF2 = tabF + N / 2;
+    const C2<float>* tabI2 = tabI + N / 2;
+    C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);
+    C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
+    C2<TF> z[16];
+    // ---- pressure: Z2 = FFT(p); keep only its contribution to b, already scaled, in float
+#ifndef NNS_P32
+#define NNS_P32 1          // 1: the pressure transform in float32 on the forward-DIFFERENCED line (precise mode); 0: float64 FFT(p)
+#endif
+    if constexpr (sizeof(TF) == 8 && NNS_P32) {
+        // p enters the residual only through its FIRST derivative.  FFT(p) in float32 would not do: its rounding noise, white
+        // in k, is amplified by k (4e-5 of |p| at N = 1024).  The forward difference d_j = p_{j+1} - p_j (exact or correctly
+        // rounded in float32) has FFT(d) = (e^{i theta} - 1) FFT(p), so
+        //     (i k / rho) FFT(p) = M FFT(d),   M = (s / 2) (cot(theta / 2) - i),   s = k cs,   |M| <= (pi / 2) |k|_max cs / theta_max:
+        // a BOUNDED filter on a float32 transform -- no amplification (3e-7 rel-L2), and one of the two
+        // float64 forward transforms per line becomes a float32 one (measured 0.62 -> 0.58 ms column pass, 0.80 -> 0.77 row pass).
+        C2<float> zf[16];
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            zf[m].x = right_of<m, N / 16>(pf, tid) - pf[m];
+            zf[m].y = 0.f;
+        });
+        fft_line<float, N, false, 0>(zf, tabI, tabI2, xbI, tid, hook);
+        int te = tid;
+        asm volatile("" : "+v"(te), "+v"(zf[0].x));
+        const float csh = (float)(0.5 * k.cs);
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            int ko, ke;
+            wavenumber<N, m>(te, ko, ke);
+            const float sh = (float)ko * csh;                               // s / 2 (0 at k = 0 and at the Nyquist mode, as the oracle drops it)
+            const float c = ctab[ke < 0 ? -ke : ke] * csh;                  // (s / 2) cot(theta / 2), even in k; ctab[k] = k_odd cot(pi k / N)
+            const float gx = c * zf[m].x + sh * zf[m].y, gy = c * zf[m].y - sh * zf[m].x;        // G = (i k / rho) FFT(p) / N
+            if constexpr (P_IN_REAL) { b[m].x = gx; b[m].y = gy; } else { b[m].x = -gy; b[m].y = gx; }   // i G in the y-pass
+        });
+    } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)pf[m]; z[m].y = (TF)0; }
+    fft_line<TF, N, false, 0>(z, tabF, tabF2, xbF, tid, hook);
+    // The per-element wavenumber factors depend only on the lane id: left alone, instruction selection
+    // computes all 16 (fp64) during the butterflies above and spills them.  Tie the lane id to the
+    // transform's output so they are computed here, where they are used.
+    int te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        int ko, ke;
+        wavenumber<N, m>(te, ko, ke);
+        const TF s = (TF)((double)ko * k.cs);
+        if constexpr (P_IN_REAL) { b[m].x = (float)(-s * z[m].y); b[m].y = (float)(s * z[m].x); }   // (i k/rho) Z2
+        else { b[m].x = (float)(-s * z[m].x); b[m].y = (float)(-s * z[m].y); }                       // i (i k/rho) Z2
+    });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- velocity: Z1 = FFT(u + i v)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { z[m].x = (TF)uf[m]; z[m].y = (TF)vf[m]; }
+    fft_line<TF, N, false, P>(z, tabF, tabF2, xbF, tid, hook);
+    int te = tid;
+    asm volatile("" : "+v"(te), "+v"(z[0].x));
+    static_for<0, 16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        int ko, ke;
+        wavenumber<N, m>(te, ko, ke);
+        const TF k1 = (TF)((double)ko * k.c1);
+        const TF k2 = (TF)((double)(ke * ke) * k.c2);                         // ke^2 <= 2^18: exact
+        a[m].x = (float)(-k1 * z[m].y); a[m].y = (float)(k1 * z[m].x);        // i k Z1
+        b[m].x += (float)(k2 * z[m].x); b[m].y += (float)(k2 * z[m].y);       // nu k^2 Z1
+    });
+    // ---- inverse transforms in float32
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true, 2 * P>(a, tabI, tabI2, xbI, tid, hook);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_line<float, N, true, 3 * P>(b, tabI, tabI2, xbI, tid, hook);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Constants of the fused FD 5-point residual (nns_residual_both_f32): the y-pass owns whole rows, so the stencil's j-1 /
+// j+1 neighbours of u and v are already in its registers (adjacent lane, or the adjacent 64-column slot at the wave's
+// ends) and the rows i-1 / i+1 are re-read from L2 -- the stencil back-end then costs no second pass over the inputs.
+struct FdK { float inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2; };
+// Row slabs of a grid sharded over ranks (nns/slab.py): the stencil's row above local row 0 / below local row nx-1 comes from
+// the neighbour rank's edge rows, delivered as [u, v, p][grid][N] messages (top / bot; stride = grids * N).  NULL: the
+// rows wrap around inside the local grid (single process).
+struct HaloK { const float* top; const float* bot; long fstride; };
+#ifndef NNS_YPASS_NT
+#define NNS_YPASS_NT 1            // non-temporal hints on the fused row pass's write-once outputs and read-once streams (0.84 -> 0.78 ms)
+#endif
+#ifndef NNS_YPASS_NT_PLAIN
+#define NNS_YPASS_NT_PLAIN 0      // the same hints in the plain (not fused) row pass
+#endif
+template <bool NT> __device__ __forceinline__ float ld_stream(const float* q) { if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; }
+template <bool NT> __device__ __forceinline__ void st_stream(float* q, float x) { if constexpr (NT) __builtin_nontemporal_store(x, q); else *q = x; }
 
 // ------------------------------------------------------------------------------------------
 // y-pass: rows (contiguous lines).  One line per TPF lanes; a workgroup iteration handles
@@ -309,163 +324,6 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                     });
                 }
             });
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// FD 5-point + spectral row pass, MARCHING (nns_residual_both_f32).  In spec_ypass_kernel<.., FUSE_FD = true> the eight
-// waves of a workgroup take eight adjacent rows and fetch the stencil's rows i-1 / i+1 again after the spectral epilogue:
-// each workgroup iteration streams 352 KB, an XCD's 4 MB L2 turns over in a third of an iteration, so two thirds of those
-// re-reads go back to the fabric (measured 4.95 GB per launch against 3.76 GB algorithmic, r01 PMC passes).  Here every line
-// (one wave at N = 1024) walks DOWN a band of R consecutive rows of one grid instead: row i+1 is the line it has already
-// prefetched for its next transform, row i-1 of u and v is its previous line, and p's j-1 / j+1 come from lane rotates like
-// u's and v's -- the stencil issues no loads except p[i-1].  Row i-1 of u, v rides through the float64 forward transforms
-// in registers and is PARKED in LDS for the rest of the iteration: the float32 inverse transforms use only the lower half of
-// the line's exchange image, the upper half (8.5 N bytes >= the 8 N needed) is free exactly when the register file is full
-// (inverse transforms, epilogue loads).  Extra traffic: two rows of u, v, p per band (2 / R of three streams) + 4 B/pt.
-// ------------------------------------------------------------------------------------------
-template <int N, typename TF>
-struct MarchLds {
-    using L = SpecLds<N, TF>;
-    static constexpr int PARK_OFF = (L::SLOTS * (int)sizeof(C2<float>) + 15) / 16 * 16;      // above the float32 exchange image
-    static constexpr int NEED = PARK_OFF + 2 * N * 4;
-    static constexpr int LINE_BYTES = ((NEED > L::LINE_BYTES ? NEED : L::LINE_BYTES) + 127) / 128 * 128;
-    static constexpr int TOTAL = L::TABF_BYTES + L::TABI_BYTES + L::LINES * LINE_BYTES;
-};
-template <int N, typename TF>
-__global__ __launch_bounds__(kSpecThreads) void both_rowpass_march_kernel(const float* __restrict__ u, const float* __restrict__ v,
-                                                                           const float* __restrict__ p, const float* __restrict__ up,
-                                                                           const float* __restrict__ vp, float* __restrict__ ru,
-                                                                           float* __restrict__ rv, float* __restrict__ rd,
-                                                                           float* __restrict__ fu, float* __restrict__ fv, float* __restrict__ fd,
-                                                                           int nx, FdK fk, int R, int bpg, long nbands, SpecK k, HaloK hk) {
-    using L = SpecLds<N, TF>;
-    using M = MarchLds<N, TF>;
-    constexpr int TPF = L::TPF;
-    constexpr bool NT = NNS_YPASS_NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
-    spec_setup<N, TF>(smem, tabF, tabI, lines);
-    const long total_lines = (long)gridDim.x * L::LINES;
-    const long rounds = (nbands + total_lines - 1) / total_lines;            // the same trip count for every line (wave-synchronous exchanges)
-    for (long rnd = 0; rnd < rounds; ++rnd) {
-        int tx = threadIdx.x;
-        asm volatile("" : "+v"(tx));
-        const int wave = tx / kWave, lane = tx % kWave;
-        const int sub = lane / TPF, tid = lane % TPF;
-        int line = wave * L::FPW + sub;
-        // one line per wave (N = 1024): the band, its grid and every row address are wave-uniform -- keep them in scalar registers
-        if constexpr (L::FPW == 1) line = __builtin_amdgcn_readfirstlane(line);
-        unsigned char* xb = lines + (size_t)line * M::LINE_BYTES;
-        float* park = reinterpret_cast<float*>(xb + M::PARK_OFF) + tid;           // [u | v][N], element tid + TPF m at park[field * N + TPF m]
-        const long band_raw = rnd * total_lines + (long)blockIdx.x * L::LINES + line;
-        const bool band_ok = band_raw < nbands;
-        const long band = band_ok ? band_raw : nbands - 1;
-        const long gi = band / bpg;
-        const int ii0 = (int)(band % bpg) * R;
-        const size_t gbase = (size_t)gi * nx * N;                               // first element of this line's grid
-        // row ii of the grid (ii in [-1, nx]): -1 / nx are the halo messages of a row slab, or wrap around inside the grid
-        auto row_ptr = [&](const float* f, int field, int ii) -> const float* {
-            if (ii < 0) return hk.top ? hk.top + field * hk.fstride + (size_t)gi * N : f + gbase + (size_t)(nx - 1) * N;
-            if (ii >= nx) return hk.bot ? hk.bot + field * hk.fstride + (size_t)gi * N : f + gbase;
-            return f + gbase + (size_t)ii * N;
-        };
-        float um[16], vm[16], nu[16], nv[16], np[16];
-        {   // band prologue: row ii0 - 1 (u, v) and row ii0
-            const float* q0 = row_ptr(u, 0, ii0 - 1) + tid; const float* q1 = row_ptr(v, 1, ii0 - 1) + tid;
-            const size_t c0 = gbase + (size_t)ii0 * N + tid;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                um[m] = q0[TPF * m]; vm[m] = q1[TPF * m];
-                nu[m] = u[c0 + TPF * m]; nv[m] = v[c0 + TPF * m]; np[m] = p[c0 + TPF * m];
-            }
-        }
-        for (int s = 0; s < R; ++s) {
-            int tidv = tid;
-            asm volatile("" : "+v"(tidv));                                         // see spec_ypass_kernel: keeps lane-invariant factors from being hoisted
-            const int ii_raw = ii0 + s;
-            const bool valid = band_ok && ii_raw < nx;
-            const int ii = ii_raw < nx ? ii_raw : nx - 1;
-            const size_t base = gbase + (size_t)ii * N + tidv;
-            float uf[16], vf[16], pf[16];
-#pragma unroll
-            for (int m = 0; m < 16; ++m) { uf[m] = nu[m]; vf[m] = nv[m]; pf[m] = np[m]; }
-            const float* nq0 = row_ptr(u, 0, ii + 1) + tidv; const float* nq1 = row_ptr(v, 1, ii + 1) + tidv; const float* nq2 = row_ptr(p, 2, ii + 1) + tidv;
-            auto hook = [&](auto sc) {
-                if constexpr (decltype(sc)::value == 2 * FftPasses<N>::value - 1) {
-                    // after the last forward pass: the float64 image is dead -- park row i-1 above the float32 image, and request
-                    // row i + 1 (the stencil's lower neighbour and the next transform's input) into the registers just freed
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) { park[TPF * m] = um[m]; park[N + TPF * m] = vm[m]; }
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) { nu[m] = nq0[TPF * m]; nv[m] = nq1[TPF * m]; np[m] = nq2[TPF * m]; }
-                }
-            };
-            C2<float> a[16], b[16];
-            asm volatile("; MARCH-PHASE transforms");
-            deriv_core<N, TF, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k, hook);
-            asm volatile("; MARCH-PHASE epilogue");
-            float pmr[16];                                                           // p[i-1]: the one neighbour row read again (4 B/pt)
-            float tu[16], tv[16];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float pu[8], pv[8], pd[8], qu[8], qv[8];
-                if (h == 1) {                                                        // requested once half of a, b is dead
-                    const float* q2 = row_ptr(p, 2, ii - 1) + tidv;
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) pmr[m] = q2[TPF * m];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const size_t c = base + TPF * (8 * h + i);
-                    pu[i] = ld_stream<NT>(ru + c); pv[i] = ld_stream<NT>(rv + c); pd[i] = ld_stream<NT>(rd + c);
-                    qu[i] = ld_stream<NT>(up + c); qv[i] = ld_stream<NT>(vp + c);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = 8 * h + i;
-                    tu[m] = __fmul_rn(uf[m] - qu[i], k.inv_dt); tv[m] = __fmul_rn(vf[m] - qv[i], k.inv_dt);
-                }
-                if (valid) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int m = 8 * h + i;
-                        const size_t c = base + TPF * m;
-                        st_stream<NT>(ru + c, __fadd_rn(__fmaf_rn(vf[m], a[m].x, __fadd_rn(tu[m], pu[i])), b[m].x));
-                        st_stream<NT>(rv + c, __fadd_rn(__fmaf_rn(vf[m], a[m].y, __fadd_rn(tv[m], pv[i])), b[m].y));
-                        st_stream<NT>(rd + c, pd[i] + a[m].y);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the stencil: rows i-1 (back from LDS), i, i+1 (landed under the inverse transforms) are all on chip
-            asm volatile("; MARCH-PHASE stencil");
-#pragma unroll
-            for (int m = 0; m < 16; ++m) { um[m] = park[TPF * m]; vm[m] = park[N + TPF * m]; }
-            static_for<0, 16>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                const size_t c = base + TPF * m;
-                const float ucc = uf[m], vcc = vf[m];
-                const float ul = left_of<m, TPF>(uf, tidv), ur = right_of<m, TPF>(uf, tidv);
-                const float vl = left_of<m, TPF>(vf, tidv), vr = right_of<m, TPF>(vf, tidv);
-                const float pl = left_of<m, TPF>(pf, tidv), pr = right_of<m, TPF>(pf, tidv);
-                const float ux = (nu[m] - um[m]) * fk.inv_2dx, uy = (ur - ul) * fk.inv_2dy;
-                const float vx = (nv[m] - vm[m]) * fk.inv_2dx, vy = (vr - vl) * fk.inv_2dy;
-                const float px = (np[m] - pmr[m]) * fk.inv_2dx, py = (pr - pl) * fk.inv_2dy;
-                const double lu = ((double)nu[m] - 2.0 * ucc + (double)um[m]) * fk.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * fk.inv_dy2;
-                const double lv = ((double)nv[m] - 2.0 * vcc + (double)vm[m]) * fk.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * fk.inv_dy2;
-                if (valid) {
-                    st_stream<NT>(fu + c, tu[m] + ucc * ux + vcc * uy + px * fk.inv_rho - fk.nu * (float)lu);
-                    st_stream<NT>(fv + c, tv[m] + ucc * vx + vcc * vy + py * fk.inv_rho - fk.nu * (float)lv);
-                    st_stream<NT>(fd + c, ux + vy);
-                }
-            });
-            asm volatile("; MARCH-PHASE carry");
-#pragma unroll
-            for (int m = 0; m < 16; ++m) { um[m] = uf[m]; vm[m] = vf[m]; }
         }
     }
 }
@@ -660,39 +518,6 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
     return check_launch("spec_residual_ypass");
 }
 
-#ifndef NNS_ROWPASS_MARCH
-#define NNS_ROWPASS_MARCH 0       // 1: marching fused row pass (both_rowpass_march_kernel), 0: spec_ypass_kernel<FUSE_FD>
-#endif
-template <int N, typename TF>
-int launch_rowpass_march(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
-                         float* fu, float* fv, float* fd, int batch, int nx, const SpecK& k, const FdK& fk, const HaloK& hk, hipStream_t s) {
-    using L = SpecLds<N, TF>;
-    using M = MarchLds<N, TF>;
-    auto kern = both_rowpass_march_kernel<N, TF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, M::TOTAL);
-        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "both rowpass: hipFuncSetAttribute(%d B): %s", M::TOTAL, hipGetErrorString(e));
-        attr_set = true;
-    }
-    // band height: as tall as keeps every line of the launch busy (halo overhead 2 / R on three of the streams), at most 64 rows
-    const long gmax = spec_grid_cap();
-    const long nrows = (long)batch * nx;
-    long grid = (nrows / 4 + L::LINES - 1) / L::LINES;                          // never more lines than bands of >= 4 rows
-    if (grid > gmax) grid = gmax;
-    if (grid < 1) grid = 1;
-    const long total_lines = grid * L::LINES;
-    long R = nrows / total_lines;
-    R = R < 4 ? 4 : (R > 64 ? 64 : R);
-    static const long r_env = [] { const char* e = getenv("NNS_MARCH_R"); return e ? atol(e) : 0L; }();      // tuning override
-    if (r_env > 0) R = r_env;
-    if (R > nx) R = nx;
-    const int bpg = (int)((nx + R - 1) / R);
-    const long nbands = (long)batch * bpg;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kSpecThreads), M::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, (int)R, bpg, nbands, k, hk);
-    return check_launch("residual_both_rowpass");
-}
-
 int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
           double Lx, double rho, double nu, int precise, hipStream_t s, int seg_rows = 0, long seg_stride = 0) {
     if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
@@ -751,14 +576,9 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     const HaloK hk{halo_top, halo_bot, (long)batch * ny};
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
-#if NNS_ROWPASS_MARCH
-        return precise ? launch_rowpass_march<N, double>(u, v, p, up, vp, ru, rv, rd, fu, fv, fd, batch, nx, k, fk, hk, s)
-                       : launch_rowpass_march<N, float>(u, v, p, up, vp, ru, rv, rd, fu, fv, fd, batch, nx, k, fk, hk, s);
-#else
         const long nrows = (long)batch * nx;
         return precise ? launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk)
                        : launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk);
-#endif
     });
 }
 
