@@ -925,7 +925,7 @@ NNS_API int nns_pixel_mlp_bwd_f32(const float* x, const float* gy, const float* 
     if (int rc = build_bwd_desc(widths_host, nlayers, d, nw, np, maxw)) return rc;
     if (!bf16 && maxw > 32) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_bwd: the float32-operand backward supports widths <= 32 (got %d); use bf16", maxw);
     if (workspace_bytes < (size_t)kBwdMaxBlocks * (maxw <= 32 ? 4 : 1) * np * sizeof(float))
-        return fail(NNS_ERR_INVALID_ARG, "pixel_mlp_bwd: workspace too small (%zu B, see nns_pixel_mlp_bwd_workspace)", workspace_bytes);
+        return fail(NNS_ERR_WORKSPACE, "pixel_mlp_bwd: workspace too small (%zu B, see nns_pixel_mlp_bwd_workspace)", workspace_bytes);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long npix = (long)mb * P;
     float* ws = static_cast<float*>(workspace);
