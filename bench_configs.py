@@ -26,6 +26,80 @@ def timeit(fn, iters=10, warm=2):
     return (time.perf_counter() - t0) / iters
 
 
+def _cpu_time(fn, budget_s=3.0, max_reps=50):
+    """Median seconds of fn() on this host (time.perf_counter), after one warm-up, within ~budget_s."""
+    fn()
+    ts, t_all = [], time.perf_counter()
+    while len(ts) < max_reps and (len(ts) < 3 or time.perf_counter() - t_all < budget_s):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def cpu_baseline_operators(n=1024):
+    """the reference's own operators -- as the NumPy float64 oracle port (oracle/chorin_fd.py,
+    oracle/direct_fd.py; bitwise the reference on the goldens) -- timed on THIS box's host, one thread (element-wise NumPy):
+    explicit predictor (src/chorin_fd/simulate.py:63-91), pressure RHS (:186-188), correction (:204-210), _build_up_b
+    (src/direct_fd/simulate.py:56-66), one Jacobi sweep (:76-86) at n x n; the lexicographic SOR loop (:190-196) at 64 x 64."""
+    from oracle import chorin_fd as OC, direct_fd as OD
+    rng = np.random.default_rng(0)
+    h = 2. / (n - 1)
+    u, v, u1, v1, p = (rng.standard_normal((n, n)) for _ in range(5))
+    rows = {}
+
+    def add(name, fn, pts, ref):
+        t, reps = _cpu_time(fn)
+        rows[name] = dict(ms=1e3 * t, Mpt_s=pts / t / 1e6, reps=reps, reference=ref)
+    add('explicit_predictor_%d' % n, lambda: OC.explicit_predictor(u, v, u1, v1, 1e-3, h, h, 0.02), n * n, 'src/chorin_fd/simulate.py:63-91')
+    add('pressure_rhs_%d' % n, lambda: OC.pressure_rhs(u, v, 1e-3, h, h, 1.0), n * n, 'src/chorin_fd/simulate.py:186-188')
+    add('correction_%d' % n, lambda: OC.correction(u, v, p, 1e-3, h, h), n * n, 'src/chorin_fd/simulate.py:204-210')
+    add('build_up_b_%d' % n, lambda: OD.build_up_b(u, v, 1e-3, h, h, 1.0), n * n, 'src/direct_fd/simulate.py:56-66')
+    b = OD.build_up_b(u, v, 1e-3, h, h, 1.0)
+    add('jacobi_sweep_%d' % n, lambda: OD.jacobi_sweep(p, b, h, h), n * n, 'src/direct_fd/simulate.py:76-86')
+    m = 64
+    hm = 2. / (m - 1)
+    pm, Cm = 0.01 * rng.standard_normal((m, m)), 0.1 * rng.standard_normal((m, m))
+    add('sor_sweep_lexicographic_64', lambda: OC.sor_sweep_lexicographic(pm, Cm, hm, hm, 1.25), m * m, 'src/chorin_fd/simulate.py:190-196 (pure-Python loop)')
+    return dict(value=rows['explicit_predictor_%d' % n]['Mpt_s'] * 1e6, unit='grid points/s (explicit predictor, %d^2)' % n, cores=1, kind='port',
+                sample='NumPy float64 oracle port on this host, median of >= 3 runs within ~3 s per operator', host_cores_present=os.cpu_count(), operators=rows)
+
+
+def cpu_baseline_cfg1(n=64, nit=50, steps=2):
+    """One chorin_fd cavity step of the oracle port on this host (the reference's CPU path: ~95 % pure-Python SOR loop)."""
+    from oracle import chorin_fd as OC
+    from oracle.boundary import cavity_bcs
+    h = 2. / (n - 1)
+    u_bc, v_bc, p_bc = cavity_bcs(h, h)
+    z = np.zeros((n, n))
+    t0 = time.perf_counter()
+    OC.simulate(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, steps, nit, 1e-3, 1.0, 0.02, 1.25, 'explicit')
+    t = (time.perf_counter() - t0) / steps
+    return dict(value=n * n / t, unit='grid-point steps/s', cores=1, kind='port', ms_per_step=1e3 * t,
+                sample='%d explicit steps of the %dx%d cavity, nit=%d, NumPy float64 oracle port (src/chorin_fd/simulate.py:212-234)' % (steps, n, n, nit),
+                host_cores_present=os.cpu_count())
+
+
+def cpu_baseline_neural(K=10, n=51, nt=100):
+    """spectral_ode.PDEFunc forward + backward on the host CPU with torch (float32, the reference's own shapes: 51 x 51, nt = 100,
+    mb = 1; src/neural_spectral/spectral_ode.py:62-81,178-190) through the oracle's restatement."""
+    from oracle import neural as ON
+    torch.manual_seed(0)
+    init = torch.randn(3 * K, requires_grad=True)
+    mlp = [torch.randn(128, 3 * K) * 0.1, torch.zeros(128), torch.randn(128, 128) * 0.1, torch.zeros(128), torch.randn(3 * K, 128) * 0.1, torch.zeros(3 * K)]
+    for t in mlp:
+        t.requires_grad_(True)
+    basis = torch.randn(K, 3, n, n, requires_grad=True)
+    obs = torch.randn(nt, 1, 3, n, n)
+    nth = torch.get_num_threads()
+
+    def fwd_bwd():
+        pred, _ = ON.pde_forward(init, mlp, basis, 1, nt)
+        ON.loss_fn(pred, obs).backward()
+    t, reps = _cpu_time(fwd_bwd, budget_s=6.0, max_reps=5)
+    return dict(value=1.0 / t, unit='training iterations/s (forward + backward)', cores=nth, kind='port', ms_per_iter=1e3 * t,
+                sample='%d x forward+backward of PDEFunc K=%d, %dx%d, nt=%d, mb=1, torch CPU float32 (%d threads)' % (reps, K, n, n, nt, nth),
+                host_cores_present=os.cpu_count())
+
+
 def cfg1():
     from nns.chorin_fd import NavierStokesSystem
     from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
@@ -53,7 +127,7 @@ def cfg1():
                                beta=1.25, method='explicit', advection='corrected', pressure_solver='redblack')
         dt = timeit(lambda: s.simulate_device(use_graph=False), iters=2, warm=1) / 200
         out['explicit_corrected_redblack_B%d_eager_ms_per_step' % B] = 1e3 * dt
-    return dict(config='cfg1 chorin_fd 64x64 cavity Re=100, nit=50, float64 (reference CPU: 0.51 s/step)', **out)
+    return dict(config='cfg1 chorin_fd 64x64 cavity Re=100, nit=50, float64', cpu_baseline=cpu_baseline_cfg1(), **out)
 
 
 def cfg2():
@@ -71,7 +145,7 @@ def cfg2():
     mlp = PixelMLP(4, 32).cuda()
     x = torch.randn(16, 3, n, n, device='cuda')
     tm = timeit(lambda: mlp(x), iters=20)
-    return dict(config='cfg2 neural_spectral 128x128 K=10 nt=100 mb=1 float32 (reference CPU 51^2: fwd 1.49 s + bwd 2.44 s)',
+    return dict(config='cfg2 neural_spectral 128x128 K=10 nt=100 mb=1 float32', cpu_baseline=cpu_baseline_neural(),
                 train_iter_ms=1e3 * timeit(it, iters=10), forward_ms=1e3 * timeit(lambda: m(obs[0], t), iters=10),
                 pixel_mlp_d4_w32_fp32_Gpix_s=16 * n * n / tm / 1e9)
 
@@ -127,10 +201,14 @@ def cfg5():
         m.loss(obs[0], t, obs).backward()
     tm = timeit(it, iters=3, warm=1)
     return dict(config='cfg5 ensemble 256 x 256x256 neural_spectral, K=10, nt=32, float32 (single GPU: all 256 members)',
-                fwd_bwd_ms=1e3 * tm, obs_GB=obs.numel() * 4 / 1e9, obs_stream_GBs=2 * obs.numel() * 4 / tm / 1e9)
+                fwd_bwd_ms=1e3 * tm, obs_GB=obs.numel() * 4 / 1e9, obs_stream_GBs=obs.numel() * 4 / tm / 1e9, note="observations are read ONCE per step (fused loss + gradient sweep)")
+
+
+def cpu_ops():
+    return dict(config='reference operators at 1024^2 on this host (BASELINE.md section 3)', cpu_baseline=cpu_baseline_operators())
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['cfg1', 'cfg2', 'cfg3', 'cfg5']
+    which = sys.argv[1:] or ['cpu_ops', 'cfg1', 'cfg2', 'cfg3', 'cfg5']
     for w in which:
         print(json.dumps(globals()[w]()), flush=True)

@@ -326,6 +326,18 @@ int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b0, const
                         const float* W2, const float* b2, const float* states, const float* grad_out,
                         float* grad_z0, float* gW0, float* gb0, float* gW1, float* gb1, float* gW2, float* gb2,
                         void* work, int mb, int K, int hidden, int Nt, int method, void* stream);
+/* The time-parallel form of that backward (anode/adjoint.py:38-70 walks the steps backwards one by one; every step's Jacobian
+ * depends only on its own stored input state, so all of them can be formed at once):
+ *   nns_ode_mlp_bwd_steps_f32  backward of `rows` INDEPENDENT single steps y -> y' of size dt: grad_y[r] = (dy'/dy)^T grad_out[r],
+ *                              parameter gradients summed over the rows (work: nns_ode_mlp_bwd_workspace(rows) bytes);
+ *   nns_ode_adjoint_chain_f32  lam[Nt-1] = g[Nt-1], lam[s-1] = g[s-1] + lam[s] J[s]: the adjoint recurrence on the K x K step
+ *                              Jacobians J [Nt][mb][K][K] (K <= 64), g, lam [Nt][mb][K].
+ * Pass 1: rows (s, b, i) with grad_out = e_i give J; chain; pass 2: rows (s, b) with grad_out = lam[s][b] give the parameter
+ * gradients and grad_z0 = grad_y of step 0 -- three launches of parallel work instead of Nt dependent steps. */
+int nns_ode_mlp_bwd_steps_f32(const float* y, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                              const float* b2, const float* grad_out, float* grad_y, float* gW0, float* gb0, float* gW1, float* gb1,
+                              float* gW2, float* gb2, void* work, int rows, int K, int hidden, double dt, int method, void* stream);
+int nns_ode_adjoint_chain_f32(const float* J, const float* g, float* lam, int Nt, int mb, int K, void* stream);
 /* Basis expansion (PDEFunc.forward, spectral_ode.py:71-79): pred[t][c][p] = sum_k coeff[t][k][c] basis[k][c][p];
  * coeff [T, K, C] (T = nt*mb), basis [K, C, P] (P = nx*ny), pred [T, C, P].  K <= 32. */
 int nns_basis_expand_f32(const float* coeff, const float* basis, float* pred, int T, int K, int C, int P, void* stream);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
                                                          float* __restrict__ gz0, float* __restrict__ gW0, float* __restrict__ gb0,
                                                          float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
                                                          float* __restrict__ gb2, float* __restrict__ work,
-                                                         int mb, int K, int Nt, int method) {
+                                                         int mb, int K, int Nt, int method, float dt_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
     float* A = carve(lds, TB * KS);
     float* ws = work + (size_t)blockIdx.x * 4 * kStageFloats;
     const int row0 = blockIdx.x * TB;
-    const float dt = 1.f / (float)Nt;
+    const float dt = dt_in > 0.f ? dt_in : 1.f / (float)Nt;          // dt_in: independent single steps of a longer integration (nns_ode_mlp_bwd_steps_f32)
     const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
     const int nstage = method == METHOD_RK4 ? 4 : (method == METHOD_RK2 ? 2 : 1);
 
@@ -799,20 +799,20 @@ NNS_API int nns_ode_mlp_fwd_f32(const float* z0, const float* W0, const float* b
     return check_launch("ode_mlp_fwd");
 }
 
-NNS_API int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
-                                const float* b2, const float* states, const float* grad_out, float* grad_z0, float* gW0, float* gb0,
-                                float* gW1, float* gb1, float* gW2, float* gb2, void* work, int mb, int K, int hidden, int Nt, int method,
-                                void* stream) {
+static int ode_mlp_bwd_impl(const char* what, const float* z0, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                            const float* b2, const float* states, const float* grad_out, float* grad_z0, float* gW0, float* gb0,
+                            float* gW1, float* gb1, float* gW2, float* gb2, void* work, int mb, int K, int hidden, int Nt, int method, float dt_in,
+                            void* stream) {
     if (!z0 || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !states || !grad_out || !grad_z0 || !gW0 || !gb0 || !gW1 || !gb1 || !gW2 || !gb2 || !work ||
         mb < 1 || Nt < 1)
-        return fail(NNS_ERR_INVALID_ARG, "ode_mlp_bwd: bad args");
-    if (hidden != H) return fail(NNS_ERR_UNSUPPORTED, "ode_mlp_bwd: hidden width %d (fixed at %d)", hidden, H);
-    if (K < 1 || K > KP) return fail(NNS_ERR_UNSUPPORTED, "ode_mlp_bwd: K=%d not in [1, %d]", K, KP);
-    if (method_id(method) < 0) return fail(NNS_ERR_INVALID_ARG, "ode_mlp_bwd: method %d", method);
+        return fail(NNS_ERR_INVALID_ARG, "%s: bad args", what);
+    if (hidden != H) return fail(NNS_ERR_UNSUPPORTED, "%s: hidden width %d (fixed at %d)", what, hidden, H);
+    if (K < 1 || K > KP) return fail(NNS_ERR_UNSUPPORTED, "%s: K=%d not in [1, %d]", what, K, KP);
+    if (method_id(method) < 0) return fail(NNS_ERR_INVALID_ARG, "%s: method %d", what, method);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ode_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds);
-        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
         attr = true;
     }
     hipStream_t s = S(stream);
@@ -823,10 +823,54 @@ NNS_API int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b
     if (e == hipSuccess) e = hipMemsetAsync(gb1, 0, H * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gW2, 0, (size_t)K * H * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gb2, 0, K * sizeof(float), s);
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_mlp_bwd: memset: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
     hipLaunchKernelGGL(ode_mlp_bwd_kernel, dim3((mb + TB - 1) / TB), dim3(NT), kBwdLds, s, z0, W0, b0, W1, b1, W2, b2, states, grad_out,
-                       grad_z0, gW0, gb0, gW1, gb1, gW2, gb2, reinterpret_cast<float*>(work), mb, K, Nt, method);
-    return check_launch("ode_mlp_bwd");
+                       grad_z0, gW0, gb0, gW1, gb1, gW2, gb2, reinterpret_cast<float*>(work), mb, K, Nt, method, dt_in);
+    return check_launch(what);
+}
+
+NNS_API int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                const float* b2, const float* states, const float* grad_out, float* grad_z0, float* gW0, float* gb0,
+                                float* gW1, float* gb1, float* gW2, float* gb2, void* work, int mb, int K, int hidden, int Nt, int method,
+                                void* stream) {
+    return ode_mlp_bwd_impl("ode_mlp_bwd", z0, W0, b0, W1, b1, W2, b2, states, grad_out, grad_z0, gW0, gb0, gW1, gb1, gW2, gb2, work, mb, K, hidden,
+                            Nt, method, 0.f, stream);
+}
+
+// Backward of `rows` INDEPENDENT single steps y -> y' of step size dt (the time-parallel adjoint, nns/neural_spectral/anode.py):
+// grad_y[r] = (d y'[r] / d y[r])^T grad_out[r], parameter gradients summed over the rows.
+NNS_API int nns_ode_mlp_bwd_steps_f32(const float* y, const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                      const float* b2, const float* grad_out, float* grad_y, float* gW0, float* gb0, float* gW1, float* gb1,
+                                      float* gW2, float* gb2, void* work, int rows, int K, int hidden, double dt, int method, void* stream) {
+    if (!(dt > 0)) return fail(NNS_ERR_INVALID_ARG, "ode_mlp_bwd_steps: dt must be > 0");
+    return ode_mlp_bwd_impl("ode_mlp_bwd_steps", y, W0, b0, W1, b1, W2, b2, y /* states: unused with one step */, grad_out, grad_y, gW0, gb0, gW1, gb1,
+                            gW2, gb2, work, rows, K, hidden, 1, method, (float)dt, stream);
+}
+
+// lam[Nt-1] = g[Nt-1];  lam[s-1] = g[s-1] + lam[s] J[s]   (row vectors; J[s][b] = d y_{s+1} / d y_s of row b, [K][K])
+__global__ __launch_bounds__(64) void ode_adjoint_chain_kernel(const float* __restrict__ J, const float* __restrict__ g, float* __restrict__ lam,
+                                                               int Nt, int mb, int K) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    __shared__ float cur[64];
+    float l = j < K ? g[((size_t)(Nt - 1) * mb + b) * K + j] : 0.f;
+    if (j < K) lam[((size_t)(Nt - 1) * mb + b) * K + j] = l;
+    for (int s = Nt - 1; s >= 1; --s) {
+        cur[j] = l;
+        __syncthreads();
+        const float* Js = J + ((size_t)s * mb + b) * K * K;
+        float acc = j < K ? g[((size_t)(s - 1) * mb + b) * K + j] : 0.f;
+        if (j < K)
+            for (int i = 0; i < K; ++i) acc = fmaf(cur[i], Js[(size_t)i * K + j], acc);
+        __syncthreads();
+        l = acc;
+        if (j < K) lam[((size_t)(s - 1) * mb + b) * K + j] = l;
+    }
+}
+
+NNS_API int nns_ode_adjoint_chain_f32(const float* J, const float* g, float* lam, int Nt, int mb, int K, void* stream) {
+    if (!J || !g || !lam || Nt < 1 || mb < 1 || K < 1 || K > 64) return fail(NNS_ERR_INVALID_ARG, "ode_adjoint_chain: bad args (Nt=%d mb=%d K=%d)", Nt, mb, K);
+    hipLaunchKernelGGL(ode_adjoint_chain_kernel, dim3(mb), dim3(64), 0, S(stream), J, g, lam, Nt, mb, K);
+    return check_launch("ode_adjoint_chain");
 }
 
 NNS_API int nns_basis_expand_f32(const float* coeff, const float* basis, float* pred, int T, int K, int C, int P, void* stream) {

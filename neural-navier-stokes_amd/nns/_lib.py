@@ -77,6 +77,8 @@ _SINGLE = {
     'nns_ode_mlp_fwd_f32': [_P] * 8 + [_I] * 5 + [_P],
     'nns_ode_mlp_bwd_f32': [_P] * 17 + [_I] * 5 + [_P],
     'nns_ode_mlp_bwd_workspace': [_I],
+    'nns_ode_mlp_bwd_steps_f32': [_P] * 16 + [_I] * 3 + [_D, _I, _P],
+    'nns_ode_adjoint_chain_f32': [_P] * 3 + [_I] * 3 + [_P],
     'nns_basis_expand_f32': [_P] * 3 + [_I] * 4 + [_P],
     'nns_basis_expand_bwd_f32': [_P] * 5 + [_I] * 4 + [_P],
     'nns_basis_loss_fwd_f32': [_P] * 4 + [_I] * 4 + [_P],

@@ -104,22 +104,45 @@ class NavierStokesSystem():
                     D[i, i] = 3 * x[i] / (2. * (1. - x[i] ** 2))
         return D[1:-1, 1:-1]
 
+    def _get_D_matrix_interior_lagrange(self, N):
+        """matrices='corrected' only: the exact derivative matrix of the interpolant on the N-2 interior nodes (barycentric
+        weights), in place of _get_D_matrix_degrees_minus_2, whose rows do not even annihilate constants (row sums ~10)."""
+        x = self._get_gauss_lobatto_points(N)[1:-1]
+        n = N - 2
+        w = np.array([1. / np.prod([x[j] - x[m] for m in range(n) if m != j]) for j in range(n)])
+        D = np.zeros((n, n))
+        for i in range(n):
+            for j in range(n):
+                if i != j:
+                    D[i, j] = w[j] / w[i] / (x[i] - x[j])
+            D[i, i] = -np.sum(D[i, :])
+        return D
+
     def _process_boundary_conditions(self, bc_list):
+        """alpha u + beta du/dx = g per side (:201-230).  Neumann data (alpha = 0, beta = 1, g = the derivative along the +axis
+        direction, as src/boundary.py:56-86 defines it) is accepted with matrices='corrected' only; the default raises
+        NotImplementedError like the reference (:218-221)."""
         vals = {}
         names = {'left': 'minus_x', 'right': 'plus_x', 'top': 'minus_y', 'bottom': 'plus_y'}     # (:204-215)
-        for bc in bc_list:
-            if bc.type == 'dirichlet':
-                if bc.boundary not in names:
-                    raise Exception('Boundary side {} not supported'.format(bc.boundary))
-                vals['alpha_' + names[bc.boundary]] = 1
-                vals['g_' + names[bc.boundary]] = bc.value
-            elif bc.type == 'neumann':
-                raise NotImplementedError                       # (:218-221)
-            else:
-                raise Exception('Boundary type {} not supported'.format(bc.type))
         for s in names.values():
             vals['beta_' + s] = 0
+        for bc in bc_list:
+            if bc.type not in ('dirichlet', 'neumann'):
+                raise Exception('Boundary type {} not supported'.format(bc.type))
+            if bc.type == 'neumann' and self.matrices != 'corrected':
+                raise NotImplementedError                       # (:218-221)
+            if bc.boundary not in names:
+                raise Exception('Boundary side {} not supported'.format(bc.boundary))
+            neu = bc.type == 'neumann'
+            vals['alpha_' + names[bc.boundary]], vals['beta_' + names[bc.boundary]] = (0, 1) if neu else (1, 0)
+            vals['g_' + names[bc.boundary]] = bc.value
         return vals
+
+    @staticmethod
+    def _fold(A, k):
+        """(A u)_int = A_fold u_int + const with the two boundary values eliminated (oracle.chorin_spectral.Setup.fold)."""
+        Af = A[1:-1, 1:-1] + 1. / k['e'] * (np.outer(A[1:-1, 0], k['b0']) + np.outer(A[1:-1, -1], k['bN']))
+        return Af, A[1:-1, 0] * k['c0'] + A[1:-1, -1] * k['cN']
 
     @staticmethod
     def _boundary_constants(D, bc, ax):
@@ -156,16 +179,34 @@ class NavierStokesSystem():
         for f in ('u', 'v'):
             kx = self._boundary_constants(self.Dx, self._bc[f], 'x')
             ky = self._boundary_constants(self.Dy, self._bc[f], 'y')
+            g = self._bc[f]
+            for k, ax in ((kx, 'x'), (ky, 'y')):               # the g-dependent constants of the two boundary values
+                k['c0'] = (k['c0_minus'] * g['g_minus_' + ax] + k['c0_plus'] * g['g_plus_' + ax]) / k['e']
+                k['cN'] = (k['cN_minus'] * g['g_minus_' + ax] + k['cN_plus'] * g['g_plus_' + ax]) / k['e']
             self._k[f] = (kx, ky)
-            Mx = self.Dx_sqr[1:-1, 1:-1] + 1. / kx['e'] * (kx['b0'] * self.Dx_sqr[1:-1, 0] + kx['bN'] * self.Dx_sqr[1:-1, -1])
-            My = self.Dy_sqr[1:-1, 1:-1] + 1. / ky['e'] * (ky['b0'] * self.Dy_sqr[1:-1, 0] + ky['bN'] * self.Dy_sqr[1:-1, -1])
+            if self.matrices == 'corrected':
+                # every derivative sees the boundary values: operators with the boundary rows folded in (outer products) and
+                # the constants the inhomogeneous data leave behind, as [n, n] device matrices the GEMMs accumulate onto
+                Mx, kxx = self._fold(self.Dx_sqr, kx)
+                My, kyy = self._fold(self.Dy_sqr, ky)
+                D1x, k1x = self._fold(self.Dx, kx)
+                D1y, k1y = self._fold(self.Dy, ky)
+                ones_r, ones_c = np.ones((1, Ny - 2)), np.ones((Nx - 2, 1))
+                self._fold_dev = getattr(self, '_fold_dev', {})
+                self._fold_dev[f] = dict(Dx=self._dev(D1x), Dy=self._dev(D1y), Mx=self._dev(Mx), My=self._dev(My),
+                                         cx=self._dev(k1x[:, None] * ones_r), cy=self._dev(ones_c * k1y[None, :]),
+                                         cxx2=self._dev(2 * kxx[:, None] * ones_r), cyy2=self._dev(2 * ones_c * kyy[None, :]))
+            else:
+                Mx = self.Dx_sqr[1:-1, 1:-1] + 1. / kx['e'] * (kx['b0'] * self.Dx_sqr[1:-1, 0] + kx['bN'] * self.Dx_sqr[1:-1, -1])
+                My = self.Dy_sqr[1:-1, 1:-1] + 1. / ky['e'] * (ky['b0'] * self.Dy_sqr[1:-1, 0] + ky['bN'] * self.Dy_sqr[1:-1, -1])
             lx, P = self._real_eig(Mx, f + '_Dx')
             ly, Q = self._real_eig(My, f + '_Dy')
             for name, val in (('Dx_lambda', lx), ('Dx_P', P), ('Dy_lambda', ly), ('Dy_Q', Q),
                               ('Dx_P_inv', np.linalg.inv(P)), ('Dy_Q_inv', np.linalg.inv(Q))):
                 setattr(self, '%s_%s' % (f, name), val)                     # reference attribute names (:174-183)
             self._helm[f] = {k: self._dev(v) for k, v in dict(lx=lx, ly=ly, P=P, Q=Q, P_inv=np.linalg.inv(P), Q_inv=np.linalg.inv(Q)).items()}
-        self.DPx, self.DPy = self._get_D_matrix_degrees_minus_2(Nx), self._get_D_matrix_degrees_minus_2(Ny)
+        DP = self._get_D_matrix_interior_lagrange if self.matrices == 'corrected' else self._get_D_matrix_degrees_minus_2
+        self.DPx, self.DPy = DP(Nx), DP(Ny)
         self.DxDPx = self.Dx[1:-1, 1:-1] @ self.DPx
         self.DyDPy = self.Dy[1:-1, 1:-1] @ self.DPy
         self.DxDPx_lambda, self.DxDPx_P = self._real_eig(self.DxDPx, 'DxDPx')
@@ -182,6 +223,10 @@ class NavierStokesSystem():
         Dx_bar = np.stack([self.Dx[1:-1, 0], self.Dx[1:-1, -1]]).T
         Dy_bar = np.stack([self.Dy[1:-1, 0], self.Dy[1:-1, -1]]).T
         self._S = d(-(Dx_bar @ u_tau + v_tau @ Dy_bar.T))
+        if self.matrices == 'corrected':
+            lam = self.DxDPx_lambda[:, None] + self.DyDPy_lambda[None, :]
+            self._null = np.argwhere(np.abs(lam) <= 1e-9 * np.abs(lam).max())         # the constant pressure: lambda_x0 + lambda_y0 = 0
+            self._Dfull = dict(Dx=d(self.Dx[1:-1, :]), Dy=d(self.Dy[1:-1, :]), DPx=d(self.DPx), DPy=d(self.DPy))
 
     # ------------------------------------------------------------------ per-step operators on the GPU
     def _boundary_vectors(self, sol, name):
@@ -197,10 +242,11 @@ class NavierStokesSystem():
                 prod = ops.cheb_gemm(bt, sol) if left else ops.cheb_gemm(sol, bt)
                 out = out + prod.reshape(-1)
             return out.contiguous()
+        corr = self.matrices == 'corrected'       # the reference leaves the constant of the last row / column out (:250,:253)
         x0 = vec(kx['b0'] / kx['e'], (kx['c0_minus'] * g['g_minus_x'] + kx['c0_plus'] * g['g_plus_x']) / kx['e'], nj, True)
-        xN = vec(kx['bN'] / kx['e'], 0.0, nj, True)
+        xN = vec(kx['bN'] / kx['e'], kx['cN'] if corr else 0.0, nj, True)
         y0 = vec(ky['b0'] / ky['e'], (ky['c0_minus'] * g['g_minus_y'] + ky['c0_plus'] * g['g_plus_y']) / ky['e'], ni, False)
-        yN = vec(ky['bN'] / ky['e'], 0.0, ni, False)
+        yN = vec(ky['bN'] / ky['e'], ky['cN'] if corr else 0.0, ni, False)
         return x0, xN, y0, yN
 
     def _predict_dev(self, un, vn, un1, vn1):
@@ -209,9 +255,18 @@ class NavierStokesSystem():
         _un, _vn, _un1, _vn1 = I(un), I(vn), I(un1), I(vn1)
         out = []
         for name, f, f1 in (('u', _un, _un1), ('v', _vn, _vn1)):
-            fx, fy = mm(D['Dx'], f), mm(f, D['Dy'], transB=True)                       # (:264-268)
-            f1x, f1y = mm(D['Dx'], f1), mm(f1, D['Dy'], transB=True)
-            fxx, fyy = mm(D['Dxx'], f), mm(f, D['Dyy'], transB=True)                   # (:270-274)
+            if self.matrices == 'corrected':
+                # folded operators + the constants of inhomogeneous data; cxx2 / cyy2 carry the explicit AND the implicit
+                # side's share (oracle.chorin_spectral.predictor_step); all-zero constants for homogeneous Dirichlet data
+                o = self._fold_dev[name]
+                acc = lambda c, A, B, tb: mm(A, B, transB=tb, beta=1.0, out=c.clone())
+                fx, fy = acc(o['cx'], o['Dx'], f, False), acc(o['cy'], f, o['Dy'], True)
+                f1x, f1y = acc(o['cx'], o['Dx'], f1, False), acc(o['cy'], f1, o['Dy'], True)
+                fxx, fyy = acc(o['cxx2'], o['Mx'], f, False), acc(o['cyy2'], f, o['My'], True)
+            else:
+                fx, fy = mm(D['Dx'], f), mm(f, D['Dy'], transB=True)                       # (:264-268)
+                f1x, f1y = mm(D['Dx'], f1), mm(f1, D['Dy'], transB=True)
+                fxx, fyy = mm(D['Dxx'], f), mm(f, D['Dyy'], transB=True)                   # (:270-274)
             F = ops.cheb_helmholtz_rhs(f, _un, _vn, _un1, _vn1, fx, fy, f1x, f1y, fxx, fyy, self.dt)
             h = self._helm[name]
             Hh = mm(mm(h['P_inv'], F), h['Q_inv'], transB=True)                        # (:285-286)
@@ -220,7 +275,31 @@ class NavierStokesSystem():
             out.append(ops.cheb_embed(sol, *self._boundary_vectors(sol, name)))
         return out[0], out[1]
 
+    def _correct_dev_corrected(self, ui, vi, p):
+        """matrices='corrected': the projection the reference's :339-383 is after (oracle.chorin_spectral.correction_step_corrected):
+        interior divergence from the boundary values u* carries (full rows of D), the constant pressure mode projected out of
+        the Uzawa solve, and the velocity update by the pressure GRADIENT (dt / rho) DP Q (the reference subtracts DxDPx Q)."""
+        D, F, mm = self._D, self._Dfull, ops.cheb_gemm
+        div = mm(F['Dx'], ui[:, 1:-1].contiguous())                                                # Dx[1:-1, :] @ u*[:, 1:-1]
+        mm(vi[1:-1, :].contiguous(), F['Dy'], transB=True, beta=1.0, out=div)                      # + v*[1:-1, :] @ Dy[1:-1, :]^T
+        Hh = mm(mm(D['PP_inv'], div, alpha=self.rho / self.dt), D['PQ_inv'], transB=True)
+        Qh = ops.cheb_diag_div(Hh, D['lpx'], D['lpy'], 0.0, 1.0, 1.0)
+        for i, j in self._null:
+            Qh[i, j] = 0.0                                                                          # pressure is defined up to a constant
+        Q = mm(D['PP'], mm(Qh, D['PQ'], transB=True))
+        I = lambda a: a[1:-1, 1:-1].contiguous()
+        ui_i, vi_i = I(ui), I(vi)
+        mm(F['DPx'], Q, alpha=-self.dt / self.rho, beta=1.0, out=ui_i)
+        mm(Q, F['DPy'], transB=True, alpha=-self.dt / self.rho, beta=1.0, out=vi_i)
+        u1, v1, p1 = ui.clone(), vi.clone(), p.clone()
+        u1[1:-1, 1:-1] = ui_i
+        v1[1:-1, 1:-1] = vi_i
+        p1[1:-1, 1:-1] = Q
+        return u1, v1, p1
+
     def _correct_dev(self, ui, vi, p):
+        if self.matrices == 'corrected':
+            return self._correct_dev_corrected(ui, vi, p)
         D, mm = self._D, ops.cheb_gemm
         I = lambda a: a[1:-1, 1:-1].contiguous()
         ui_i, vi_i = I(ui), I(vi)

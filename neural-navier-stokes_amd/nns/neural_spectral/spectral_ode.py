@@ -116,8 +116,11 @@ class PDEFunc(nn.Module):
         ])
 
     def _coeff(self, mb, nt):
-        coeff = odesolver(self.basis_coeffs, self.init_coeffs.unsqueeze(0).repeat(mb, 1), {'Nt': nt, 'method': 'RK4'})
-        return coeff.view(nt * mb, self.K, 3)                       # (:71) view(nt, mb, K, 3)
+        # The reference integrates mb COPIES of the one init_coeffs (:69 repeat, :70): every member of the batch follows the same
+        # trajectory.  It is integrated once and broadcast; the backward of the broadcast sums the members' gradients, so the ODE
+        # adjoint runs on ONE row (time-parallel, anode._OdeMlpFn) instead of mb identical ones.
+        coeff = odesolver(self.basis_coeffs, self.init_coeffs.unsqueeze(0), {'Nt': nt, 'method': 'RK4'})      # [nt, 1, 3K]
+        return coeff.expand(nt, mb, 3 * self.K).reshape(nt * mb, self.K, 3)                                     # (:71) view(nt, mb, K, 3)
 
     def _basis(self):
         return torch.stack([f for f in self.basis_fns]).reshape(self.K, 3, self.nx * self.ny)

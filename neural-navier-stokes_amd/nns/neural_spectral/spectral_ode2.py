@@ -28,8 +28,8 @@ class PDEFunc(nn.Module):
         cs = []
         for init, f in ((self.u_init_coeffs, self.u_basis_coeffs), (self.v_init_coeffs, self.v_basis_coeffs),
                         (self.p_init_coeffs, self.p_basis_coeffs)):
-            c = odesolver(f, init.unsqueeze(0).repeat(mb, 1), {'Nt': nt, 'method': 'RK4'})      # [nt, mb, K]  (:75-83)
-            cs.append(c.reshape(nt * mb, self.K))
+            c = odesolver(f, init.unsqueeze(0), {'Nt': nt, 'method': 'RK4'})                     # [nt, 1, K]: mb identical copies (:75-83)
+            cs.append(c.expand(nt, mb, self.K).reshape(nt * mb, self.K))
         return torch.stack(cs, dim=2)                                                             # [T, K, 3]
 
     def _basis(self):

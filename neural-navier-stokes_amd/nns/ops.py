@@ -431,6 +431,29 @@ def ode_mlp_bwd(z0, W0, b0, W1, b1, W2, b2, states, grad_out, Nt, method):
     return gz0, gs
 
 
+def ode_mlp_bwd_steps(y, W0, b0, W1, b1, W2, b2, grad_out, dt, method):
+    """Backward of rows INDEPENDENT single steps of size dt (nns_ode_mlp_bwd_steps_f32): returns (grad_y [rows, K], parameter
+    gradients summed over the rows)."""
+    _f32(y, W0, b0, W1, b1, W2, b2, grad_out)
+    rows, K = y.shape
+    gy = torch.empty_like(y)
+    gs = [torch.empty_like(t) for t in (W0, b0, W1, b1, W2, b2)]
+    work = torch.empty(_lib.lib().nns_ode_mlp_bwd_workspace(rows) // 4, dtype=torch.float32, device=y.device)
+    check(_lib.lib().nns_ode_mlp_bwd_steps_f32(_p(y), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2), _p(grad_out), _p(gy),
+                                               *[_p(g) for g in gs], _p(work), rows, K, W1.shape[0], float(dt), ODE_METHODS[method], _stream()),
+          'nns_ode_mlp_bwd_steps_f32')
+    return gy, gs
+
+
+def ode_adjoint_chain(J, g):
+    """lam[Nt-1] = g[Nt-1], lam[s-1] = g[s-1] + lam[s] @ J[s] for J [Nt, mb, K, K], g [Nt, mb, K] (nns_ode_adjoint_chain_f32)."""
+    _f32(J, g)
+    Nt, mb, K = g.shape
+    lam = torch.empty_like(g)
+    check(_lib.lib().nns_ode_adjoint_chain_f32(_p(J), _p(g), _p(lam), Nt, mb, K, _stream()), 'nns_ode_adjoint_chain_f32')
+    return lam
+
+
 def basis_expand(coeff, basis):
     """coeff [T, K, C], basis [K, C, P] -> pred [T, C, P]"""
     _f32(coeff, basis)

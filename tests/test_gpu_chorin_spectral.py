@@ -111,3 +111,85 @@ def test_corrected_matrices_option(N, gpu_device):
     got = s._predictor_step(*fields)
     want = OS.predictor_step(S, *fields, dt)
     assert rel_l2(got[0], want[0]) < 1e-8 and rel_l2(got[1], want[1]) < 1e-8
+
+
+def _bc_objs(kinds, values, h):
+    from src.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as Nm
+    return [(Nm if k == 'neumann' else D)(v, s, h, h) for k, v, s in zip(kinds, values, ('left', 'right', 'top', 'bottom'))]
+
+
+@pytest.mark.parametrize('N', [17, 33])
+def test_corrected_path_neumann_and_inhomogeneous_data(N, gpu_device):
+    """matrices='corrected' accepts Neumann data (the reference raises NotImplementedError, :218-221) and
+    folds the boundary values into every derivative.  Analytic answers of one predictor step, (2 - dt lap) u* = (2 + dt lap) u
+    at tiny amplitude: Neumann and mixed heat eigenfunctions decay by the Crank-Nicolson factor, harmonic profiles carried by
+    inhomogeneous Dirichlet / Neumann data stay put; and the GPU path equals the oracle's corrected path."""
+    from src.chorin_spectral.simulate import NavierStokesSystem
+    from oracle import chorin_spectral as OS
+    h, dt, eps = 2. / N, 1e-3, 1e-7
+    fac = (2 - 2 * np.pi**2 * dt) / (2 + 2 * np.pi**2 * dt)
+    mk = lambda kinds, values: NavierStokesSystem(None, None, None, _bc_objs(kinds, values, h), _bc_objs(kinds, values, h), nt=1, nit=1, nx=N, ny=N,
+                                                  dt=dt, rho=1.0, nu=1.0, matrices='corrected')
+    s = mk(['neumann'] * 4, [0.0] * 4)
+    x, y = s.x_i[:, None], s.y_i[None, :]
+    inner = lambda a: a[1:-1, 1:-1]
+    f = np.cos(np.pi * x) * np.cos(np.pi * y)                                    # df/dn = 0 on every side
+    ui, _ = s._predictor_step(eps * f, eps * f, eps * f, eps * f)
+    assert np.abs(inner(ui / eps - fac * f)).max() < 1e-8
+    assert np.abs((ui / eps - fac * f)[0, 1:-1]).max() < 1e-8 and np.abs((ui / eps - fac * f)[1:-1, -1]).max() < 1e-8      # the walls move too
+    s = mk(['dirichlet', 'dirichlet', 'neumann', 'neumann'], [0.0] * 4)
+    f = np.sin(np.pi * x) * np.cos(np.pi * y)
+    ui, _ = s._predictor_step(eps * f, eps * f, eps * f, eps * f)
+    assert np.abs(inner(ui / eps - fac * f)).max() < 1e-8
+    s = mk(['dirichlet', 'dirichlet', 'neumann', 'neumann'], [0.0, eps, 0.0, 0.0])        # u = 0 at x = -1 ('left'), eps at x = +1
+    f = eps * (1 + x) / 2 * np.ones_like(y)
+    ui, _ = s._predictor_step(f, f, f, f)
+    assert np.abs(ui - f)[:, 1:-1].max() < 1e-8 * eps * 10
+    s = mk(['neumann'] * 4, [eps, eps, 0.0, 0.0])                                           # du/dx = eps on both x sides
+    f = eps * x * np.ones_like(y)
+    ui, _ = s._predictor_step(f, f, f, f)
+    assert np.abs(ui - f)[:, 1:-1].max() < 1e-8 * eps * 10
+    with pytest.raises(NotImplementedError):                                                 # the default still mirrors the reference
+        NavierStokesSystem(None, None, None, _bc_objs(['neumann'] * 4, [0.0] * 4, h), _bc_objs(['dirichlet'] * 4, [0.0] * 4, h), nx=N, ny=N)
+    # GPU == oracle on random fields with mixed, inhomogeneous data
+    kinds, vals = ['neumann', 'dirichlet', 'dirichlet', 'neumann'], [0.3, -0.2, 0.1, 0.4]
+    s = mk(kinds, vals)
+    tup = [(k, sd, v, h, h) for k, v, sd in zip(kinds, vals, ('left', 'right', 'top', 'bottom'))]
+    S = OS.Setup(N, N, tup, tup, corrected=True)
+    rng = np.random.default_rng(N)
+    fields = [0.1 * rng.standard_normal((N, N)) for _ in range(4)]
+    got, want = s._predictor_step(*fields), OS.predictor_step(S, *fields, dt)
+    assert rel_l2(got[0], want[0]) < 1e-8 and rel_l2(got[1], want[1]) < 1e-8
+
+
+@pytest.mark.parametrize('N', [17, 33])
+def test_corrected_projection_is_well_conditioned(N, gpu_device):
+    """The corrected correction step (exact interior pressure derivative, constant pressure mode projected out, gradient update):
+    a TIGHT check of a11's second half, which the reference's near-singular operator only allows to a forward-error bound --
+    u* = (dt / rho) grad(phi) with no normal flux through the walls is projected to zero velocity and p = phi (up to a constant);
+    random data lose all of their interior divergence but the incompatible constant; GPU == oracle to 1e-9."""
+    from src.chorin_spectral.simulate import NavierStokesSystem
+    from oracle import chorin_spectral as OS
+    h, dt, rho = 2. / N, 1e-3, 1.3
+    bcs = _bc_objs(['dirichlet'] * 4, [0.0] * 4, h)
+    s = NavierStokesSystem(None, None, None, bcs, bcs, nt=1, nit=1, nx=N, ny=N, dt=dt, rho=rho, nu=1.0, matrices='corrected')
+    lam = np.sort(np.abs(s.DxDPx_lambda))
+    assert lam[0] < 1e-10 and abs(lam[1] - np.pi**2 / 4) < 1e-6                  # the Neumann Laplacian's spectrum: 0, (pi/2)^2, ...
+    x, y = s.x_i[:, None], s.y_i[None, :]
+    phi = np.cos(np.pi * x) * np.cos(np.pi * y)
+    ui = dt / rho * (-np.pi * np.sin(np.pi * x) * np.cos(np.pi * y))
+    vi = dt / rho * (-np.pi * np.cos(np.pi * x) * np.sin(np.pi * y))
+    u1, v1, p1 = s._correction_step(ui, vi, np.zeros((N, N)))
+    Q, ph = p1[1:-1, 1:-1], phi[1:-1, 1:-1]
+    assert np.abs(u1[1:-1, 1:-1]).max() < 1e-8 * np.abs(ui).max() and np.abs(v1[1:-1, 1:-1]).max() < 1e-8 * np.abs(vi).max()
+    assert np.abs((Q - Q.mean()) - (ph - ph.mean())).max() < 1e-8
+    tup = [('dirichlet', sd, 0.0, h, h) for sd in ('left', 'right', 'top', 'bottom')]
+    S = OS.Setup(N, N, tup, tup, corrected=True)
+    rng = np.random.default_rng(N + 1)
+    ui, vi, p = (rng.standard_normal((N, N)) for _ in range(3))
+    got, want = s._correction_step(ui, vi, p), OS.correction_step_corrected(S, ui, vi, p, dt, rho)
+    for a, b in zip(got, want):
+        assert rel_l2(a, b) < 1e-9
+    div = s.Dx[1:-1, :] @ got[0][:, 1:-1] + got[1][1:-1, :] @ s.Dy[1:-1, :].T
+    div0 = s.Dx[1:-1, :] @ ui[:, 1:-1] + vi[1:-1, :] @ s.Dy[1:-1, :].T
+    assert np.abs(div - div.mean()).max() < 1e-9 * np.abs(div0).max()

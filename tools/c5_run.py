@@ -1,11 +1,14 @@
-"""Developer helper: the fused basis loss forward / backward at the BASELINE config 5 shape, for rocprofv3."""
+"""Developer helper: the BASELINE config 5 training step (ensemble 256 x 256^2, K = 10, nt = 32) -- PDEFunc.loss(...).backward() through
+the one-sweep fused basis loss -- for rocprofv3 --kernel-trace --stats."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'neural-navier-stokes_amd'))
 import torch
-from nns import ops
+from nns.neural_spectral.spectral_ode import PDEFunc
 K, n, nt, mb = 10, 256, 32, 256
-T, C, P = nt * mb, 3, n * n
-coeff = torch.randn(T, K, C, device='cuda'); basis = torch.randn(K, C, P, device='cuda'); obs = torch.randn(T, C, P, device='cuda')
-for _ in range(3):
-    ops.basis_loss_fwd(coeff, basis, obs); ops.basis_loss_bwd(coeff, basis, obs, 0.5)
+m = PDEFunc(K, n, n).cuda()
+obs = torch.randn(nt, mb, 3, n, n, device='cuda')
+t = torch.arange(nt, device='cuda') + 1
+for _ in range(4):
+    m.zero_grad()
+    m.loss(obs[0], t, obs).backward()
 torch.cuda.synchronize()
