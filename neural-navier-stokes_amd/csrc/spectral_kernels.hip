@@ -302,6 +302,8 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                     constexpr int m = 8 * h + i;
                     um[i] = um_p[TPF * m]; un_[i] = un_p[TPF * m]; vm[i] = vm_p[TPF * m]; vn_[i] = vn_p[TPF * m];
                     pm[i] = pm_p[TPF * m]; pn_[i] = pn_p[TPF * m];
+                    // (p's j-1 / j+1 by lane rotates of the row, like u's and v's, keeps pf live through the stencil: 21 spilled
+                    //  registers and 0.78 -> 0.91 ms, same-box A/B in round 2 -- they are read again from cache instead)
                     if constexpr (m == 0) pl[i] = pl0_p[0]; else pl[i] = pl_p[TPF * m];
                     if constexpr (m == 15) pr[i] = pr15_p[0]; else pr[i] = pr_p[TPF * m];
                 });
