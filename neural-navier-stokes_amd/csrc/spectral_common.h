@@ -52,20 +52,20 @@ __device__ __forceinline__ void wavenumber(int te, int& k_odd, int& k_even) {
     if constexpr (M == 8) k_odd = te == 0 ? 0 : k_even; else k_odd = k_even;
 }
 
-template <int N, typename TF>
+template <int N, typename TF, int NTHREADS = kSpecThreads>
 __device__ __forceinline__ void spec_setup(unsigned char* smem, C2<TF>*& tabF, C2<float>*& tabI, unsigned char*& lines) {
     using L = SpecLds<N, TF>;
     tabF = reinterpret_cast<C2<TF>*>(smem);
-    fill_twiddles<TF, N>(tabF, threadIdx.x, kSpecThreads);
-    fill_twiddles2<TF, N>(tabF + N / 2, threadIdx.x, kSpecThreads);
+    fill_twiddles<TF, N>(tabF, threadIdx.x, NTHREADS);
+    fill_twiddles2<TF, N>(tabF + N / 2, threadIdx.x, NTHREADS);
     if constexpr (sizeof(TF) == 4) {
         tabI = reinterpret_cast<C2<float>*>(smem);
     } else {
         tabI = reinterpret_cast<C2<float>*>(smem + L::TABF_BYTES);
-        fill_twiddles<float, N>(tabI, threadIdx.x, kSpecThreads);
-        fill_twiddles2<float, N>(tabI + N / 2, threadIdx.x, kSpecThreads);
+        fill_twiddles<float, N>(tabI, threadIdx.x, NTHREADS);
+        fill_twiddles2<float, N>(tabI + N / 2, threadIdx.x, NTHREADS);
         float* ctab = reinterpret_cast<float*>(tabI + N / 2 + Pass2<N>::ENTRIES);
-        for (int kk = threadIdx.x; kk <= N / 2; kk += kSpecThreads) {
+        for (int kk = threadIdx.x; kk <= N / 2; kk += NTHREADS) {
             double sn, cs;
             sincospi((double)kk / (double)N, &sn, &cs);
             ctab[kk] = (kk == 0 || kk == N / 2) ? 0.f : (float)((double)kk * cs / sn);

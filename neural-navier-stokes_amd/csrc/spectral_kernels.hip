@@ -476,6 +476,171 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// x-pass, ROLE-SPLIT form (round 2).  spec_xpass_kernel above lets its eight transform waves also move the tile: loads trickled
+// into the transforms, but the 3072 store row pieces of a tile are a burst in which no wave computes (7 of a tile's 19 us), and
+// keeping the next tile in registers costs every wave 48 VGPRs.  Here a workgroup has TWELVE waves: eight TRANSFORM waves (one line
+// each, as before, now with no global memory instruction at all) and four MEMORY waves that own the tile traffic: while the
+// transform waves work on tile t they store tile t-1's partials from their registers and load tile t+1's inputs into the same
+// registers (96 per lane); after the transforms ONE exchange step swaps LDS staging contents -- the memory waves take tile t's
+// results out of the staging image and put tile t+1's inputs in, element for element (same slot) -- between two workgroup
+// barriers.  The row-piece traffic (the 0.43 ms skeleton of this pass) then runs entirely under the transforms.  Without the
+// prefetch registers the transform waves fit 3 waves per SIMD (<= 168 VGPRs), which is what gives the four extra waves a home.
+// ------------------------------------------------------------------------------------------
+constexpr int kSplitThreads = kSpecThreads + 256;
+template <int N, typename TF>
+struct SplitLds {
+    using L = SpecLds<N, TF>;
+    static constexpr int SKEW_DW = N == 64 ? 4 : 8;      // dwords of skew per line (mod 8 lines): the 16-lane groups of the memory waves' b128 exchange hit 64 distinct banks
+                                                         // (N = 64: 128 lines per workgroup, half the skew keeps the image inside 160 KB)
+    static constexpr int STAGE_BYTES = 3 * L::STAGE_F * 4 + 8 * SKEW_DW * 4;
+    static constexpr int LINE_BYTES = ((L::XB_BYTES > STAGE_BYTES ? L::XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
+    static constexpr int TOTAL = L::TABF_BYTES + L::TABI_BYTES + L::LINES * LINE_BYTES;
+};
+template <int N, typename TF, bool SEG>
+__global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                          const float* __restrict__ p, float* __restrict__ ru,
+                                                                          float* __restrict__ rv, float* __restrict__ rd,
+                                                                          int ny, int tiles_per_grid, long ntiles, SpecK k, SegK sg) {
+    using L = SpecLds<N, TF>;
+    using SL = SplitLds<N, TF>;
+    constexpr int TPF = L::TPF, CW = L::LINES, SF = L::STAGE_F;
+    constexpr int MROWS = 256 / CW;                       // rows of the tile one memory-wave instruction step covers
+    constexpr int NR = N / MROWS;                         // elements per memory lane and field (= 32 for every N)
+    static_assert(NR == 32, "tile geometry");
+    // a memory lane owns rows 4 cr .. 4 cr + 3 of every block of 4 MROWS rows: element i <-> row 4 cr + (i & 3) + 4 MROWS (i >> 2), so
+    // that its four consecutive rows move through LDS as ONE 16-byte access (24 + 24 LDS instructions per exchange instead of 96 + 96)
+    static_assert(SL::TOTAL <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, TF, kSplitThreads>(smem, tabF, tabI, lines);
+#ifndef NNS_SPLIT_EXP
+#define NNS_SPLIT_EXP 0            // timing experiments (wrong results): 1 = no transforms, 2 = no global traffic
+#endif
+    auto tile_coords = [&](long t, int& j0, size_t& g) {
+        const long lt = NNS_XPASS_REVERSE ? ntiles - 1 - (long)xcd_remap((unsigned)t, (unsigned)ntiles) : (long)xcd_remap((unsigned)t, (unsigned)ntiles);
+        j0 = (int)(lt % tiles_per_grid) * CW;
+        g = (size_t)(lt / tiles_per_grid) * (SEG ? ((size_t)ny << sg.shift) : (size_t)N * ny);
+    };
+    long t = blockIdx.x;
+    if (t >= ntiles) return;                               // uniform over the workgroup (the launch never has more workgroups than tiles)
+    if (threadIdx.x >= kSpecThreads) {
+        // ================= memory waves =================
+        int mt = threadIdx.x - kSpecThreads;
+        asm volatile("" : "+v"(mt));
+        const int cc = mt % CW, cr = mt / CW;
+        float* stage = reinterpret_cast<float*>(lines + (size_t)cc * SL::LINE_BYTES) + (cc % 8) * SL::SKEW_DW + 4 * cr;       // [field][row]
+        float R[3][NR];
+        // addresses: a uniform grid base (scalar registers) + a 32-bit element offset per lane, recomputed per tile from an opaque
+        // seed (left alone, the compiler keeps 32 precomputed 64-bit row offsets alive across the whole loop and spills them)
+        // (a lane's four consecutive rows never straddle a segment: seg_rows is a power of two >= 4, checked on the host)
+        auto off32 = [&](int i, unsigned seed, unsigned crv) -> unsigned {
+            const unsigned r0 = 4u * crv + 4u * MROWS * (unsigned)(i >> 2);
+            unsigned o;
+            if constexpr (SEG) o = (r0 >> sg.shift) * (unsigned)sg.stride + (r0 & ((1u << sg.shift) - 1u)) * (unsigned)ny;
+            else o = r0 * (unsigned)ny;
+            return seed + o + (unsigned)(i & 3) * (unsigned)ny;
+        };
+        auto load_tile = [&](long tt) {
+            int j0; size_t g;
+            tile_coords(tt, j0, g);
+            unsigned col = (unsigned)(j0 + cc < ny ? j0 + cc : ny - 1);       // clamped column: no mask needed on a load
+            unsigned crv = (unsigned)cr;
+            asm volatile("" : "+v"(col), "+v"(crv));
+            const float* ug = u + g; const float* vg = v + g; const float* pg = p + g;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const unsigned c = off32(i, col, crv);
+                R[0][i] = ug[c]; R[1][i] = vg[c]; R[2][i] = pg[c];
+            }
+        };
+        auto store_tile = [&](long tt) {
+            int j0; size_t g;
+            tile_coords(tt, j0, g);
+            if (j0 + cc < ny) {
+                unsigned col = (unsigned)(j0 + cc);
+                unsigned crv = (unsigned)cr;
+                asm volatile("" : "+v"(col), "+v"(crv));
+                float* ug = ru + g; float* vg = rv + g; float* pg = rd + g;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const unsigned c = off32(i, col, crv);
+                    ug[c] = R[0][i]; vg[c] = R[1][i]; pg[c] = R[2][i];
+                }
+            }
+        };
+        load_tile(t);
+#pragma unroll
+        for (int q = 0; q < NR / 4; ++q)
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+                *reinterpret_cast<float4*>(stage + f * SF + 4 * MROWS * q) = make_float4(R[f][4 * q], R[f][4 * q + 1], R[f][4 * q + 2], R[f][4 * q + 3]);
+        __syncthreads();                                                        // inputs of the first tile are staged
+        long prev = -1;
+        for (; t < ntiles; t += gridDim.x) {
+            const long tn = t + gridDim.x;
+            const bool has_next = tn < ntiles;
+            if (NNS_SPLIT_EXP != 2) {
+            if (prev >= 0) store_tile(prev);                                    // under the transforms of tile t: tile t-1's partials out ...
+            if (has_next) load_tile(tn);                                        // ... and tile t+1's inputs in (same registers)
+            }
+            __syncthreads();                                                    // (1) the transform waves have written tile t's partials to the staging image
+            // the exchange step: results out of the image, next inputs into it, slot for slot
+#pragma unroll
+            for (int q = 0; q < NR / 4; ++q) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    float4* slot = reinterpret_cast<float4*>(stage + f * SF + 4 * MROWS * q);
+                    const float4 out = *slot;
+                    if (has_next) *slot = make_float4(R[f][4 * q], R[f][4 * q + 1], R[f][4 * q + 2], R[f][4 * q + 3]);
+                    R[f][4 * q] = out.x; R[f][4 * q + 1] = out.y; R[f][4 * q + 2] = out.z; R[f][4 * q + 3] = out.w;
+                }
+                if (q & 1) __builtin_amdgcn_sched_barrier(0);                  // two row groups in flight at a time: all 24 reads hoisted above the writes would double the live registers
+            }
+            __syncthreads();                                                    // (2) tile t+1's inputs are staged
+            prev = t;
+        }
+        store_tile(prev);
+        return;
+    }
+    // ================= transform waves =================
+    __syncthreads();                                                            // inputs of the first tile are staged
+    for (; t < ntiles; t += gridDim.x) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        const int line = wave * L::FPW + sub;
+        unsigned char* xb = lines + (size_t)line * SL::LINE_BYTES;
+        float* my_stage = reinterpret_cast<float*>(xb) + (line % 8) * SL::SKEW_DW;
+        int tidv = tid;
+        asm volatile("" : "+v"(tidv));
+        float uf[16], vf[16], pf[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            uf[m] = my_stage[0 * SF + tidv + TPF * m]; vf[m] = my_stage[1 * SF + tidv + TPF * m]; pf[m] = my_stage[2 * SF + tidv + TPF * m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        C2<float> a[16], b2[16];
+        if (NNS_SPLIT_EXP == 1) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { a[m].x = vf[m]; a[m].y = pf[m]; b2[m].x = uf[m]; b2[m].y = vf[m]; }
+        } else
+        deriv_core<N, TF, true>(uf, vf, pf, a, b2, tabF, tabI, xb, tidv, k);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            my_stage[0 * SF + tidv + TPF * m] = uf[m] * a[m].x + b2[m].x;     // P_u = u u_x + p_x/rho - nu u_xx
+            my_stage[1 * SF + tidv + TPF * m] = uf[m] * a[m].y + b2[m].y;     // P_v = u v_x - nu v_xx
+            my_stage[2 * SF + tidv + TPF * m] = a[m].x;                       // P_d = u_x
+        }
+        __syncthreads();                                                        // (1)
+        __syncthreads();                                                        // (2)
+    }
+}
+
 // Tile order: the x-pass walks the grids from the LAST to the first and the y-pass from the first to the last, so the
 // y-pass starts on the partials (and inputs) the x-pass touched last -- part of them is still in the 256 MB Infinity
 // Cache -- and an x-pass that follows a forward-streaming kernel over the same inputs (the FD residual in bench.py)
@@ -487,6 +652,23 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
     const int tiles_per_grid = (ny + L::LINES - 1) / L::LINES;
     const long ntiles = (long)batch * tiles_per_grid;
     // prefetch is disabled where hipcc (ROCm 7.2) spills with it: checked with -Rpass-analysis=kernel-resource-usage
+#ifndef NNS_XPASS_SPLIT
+#define NNS_XPASS_SPLIT 1          // 1: spec_xpass_split_kernel (8 transform waves + 4 memory waves), 0: spec_xpass_kernel
+#endif
+    if constexpr (NNS_XPASS_SPLIT) {
+        auto kern = spec_xpass_split_kernel<N, TF, SEG>;
+        using SL = SplitLds<N, TF>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SL::TOTAL);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec xpass: hipFuncSetAttribute(%d B): %s", SL::TOTAL, hipGetErrorString(e));
+            attr_set = true;
+        }
+        const long gmax = spec_grid_cap();
+        const unsigned grid = (unsigned)(ntiles < gmax ? ntiles : gmax);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kSplitThreads), SL::TOTAL, s, u, v, p, ru, rv, rd, ny, tiles_per_grid, ntiles, k, sg);
+        return check_launch("spec_residual_xpass");
+    }
     constexpr bool PF = !((N == 128 && sizeof(TF) == 4) || N == 256);
     auto kern = spec_xpass_kernel<N, TF, PF, SEG>;
     static bool attr_set = false;
@@ -528,8 +710,8 @@ int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, 
     const double ks = 2.0 * M_PI / Lx;
     SpecK k{ks / nx, ks / (rho * nx), nu * ks * ks / nx, 0.f};
     if (seg_rows) {
-        if (seg_rows < 1 || seg_rows > nx || (seg_rows & (seg_rows - 1)) || seg_stride < (long)seg_rows * ny)
-            return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass_seg: seg_rows=%d must be a power of two <= nx=%d and seg_stride=%ld >= seg_rows * ny", seg_rows, nx, seg_stride);
+        if (seg_rows < 4 || seg_rows > nx || (seg_rows & (seg_rows - 1)) || seg_stride < (long)seg_rows * ny)
+            return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass_seg: seg_rows=%d must be a power of two in [4, nx=%d] and seg_stride=%ld >= seg_rows * ny", seg_rows, nx, seg_stride);
         SegK sg{__builtin_ctz((unsigned)seg_rows), seg_stride};
         return dispatch_n(nx, [&](auto n) {
             constexpr int N = decltype(n)::value;
