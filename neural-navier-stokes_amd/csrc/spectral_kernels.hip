@@ -160,7 +160,7 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
 // Constants of the fused FD 5-point residual (nns_residual_both_f32): the y-pass owns whole rows, so the stencil's j-1 /
 // j+1 neighbours of u and v are already in its registers (adjacent lane, or the adjacent 64-column slot at the wave's
 // ends) and the rows i-1 / i+1 are re-read from L2 -- the stencil back-end then costs no second pass over the inputs.
-struct FdK { float inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2; };
+struct FdK { float inv_2dx, inv_2dy, inv_rho, nu; double inv_dx2, inv_dy2; float inv_dx2f, inv_dy2f; };
 // Row slabs of a grid sharded over ranks (nns/slab.py): the stencil's row above local row 0 / below local row nx-1 comes from
 // the neighbour rank's edge rows, delivered as [u, v, p][grid][N] messages (top / bot; stride = grids * N).  NULL: the
 // rows wrap around inside the local grid (single process).
@@ -320,10 +320,23 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                         const float ux = (un_[i] - um[i]) * fk.inv_2dx, uy = (ur - ul) * fk.inv_2dy;
                         const float vx = (vn_[i] - vm[i]) * fk.inv_2dx, vy = (vr - vl) * fk.inv_2dy;
                         const float px = (pn_[i] - pm[i]) * fk.inv_2dx, py = (pr[i] - pl[i]) * fk.inv_2dy;
-                        const double lu = ((double)un_[i] - 2.0 * ucc + (double)um[i]) * fk.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * fk.inv_dy2;
-                        const double lv = ((double)vn_[i] - 2.0 * vcc + (double)vm[i]) * fk.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * fk.inv_dy2;
-                        st_stream<NNS_YPASS_NT>(fu + c, tu[m] + ucc * ux + vcc * uy + px * fk.inv_rho - fk.nu * (float)lu);
-                        st_stream<NNS_YPASS_NT>(fv + c, tv[m] + ucc * vx + vcc * vy + py * fk.inv_rho - fk.nu * (float)lv);
+#ifndef NNS_FUSED_LAP32
+#define NNS_FUSED_LAP32 1         // 1: second differences as differences of (exact) first differences in float32; 0: float64 sums
+#endif
+                        float lu, lv;
+                        if constexpr (NNS_FUSED_LAP32) {
+                            // (a - c) - (c - b): neighbouring values of a resolved field are within a factor 2 of each other, so both
+                            // first differences are EXACT in float32 (Sterbenz) and the only rounding is relative to the second
+                            // difference itself -- the accuracy of the float64 sum without ~28 double-rate instructions per point
+                            // (this pass is VALU-issue-bound, unlike the standalone stencil kernel, which keeps the float64 form)
+                            lu = ((un_[i] - ucc) - (ucc - um[i])) * fk.inv_dx2f + ((ur - ucc) - (ucc - ul)) * fk.inv_dy2f;
+                            lv = ((vn_[i] - vcc) - (vcc - vm[i])) * fk.inv_dx2f + ((vr - vcc) - (vcc - vl)) * fk.inv_dy2f;
+                        } else {
+                            lu = (float)(((double)un_[i] - 2.0 * ucc + (double)um[i]) * fk.inv_dx2 + ((double)ur - 2.0 * ucc + (double)ul) * fk.inv_dy2);
+                            lv = (float)(((double)vn_[i] - 2.0 * vcc + (double)vm[i]) * fk.inv_dx2 + ((double)vr - 2.0 * vcc + (double)vl) * fk.inv_dy2);
+                        }
+                        st_stream<NNS_YPASS_NT>(fu + c, tu[m] + ucc * ux + vcc * uy + px * fk.inv_rho - fk.nu * lu);
+                        st_stream<NNS_YPASS_NT>(fv + c, tv[m] + ucc * vx + vcc * vy + py * fk.inv_rho - fk.nu * lv);
                         st_stream<NNS_YPASS_NT>(fd + c, ux + vy);
                     });
                 }
@@ -758,7 +771,8 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     }
     const double ks = 2.0 * M_PI / Ly, dx = slab ? Lx : Lx / nx, dy = Ly / ny;          // a row slab passes the grid spacing itself in Lx
     const SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
-    const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy)};
+    const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy),
+                 (float)(1.0 / (dx * dx)), (float)(1.0 / (dy * dy))};
     const HaloK hk{halo_top, halo_bot, (long)batch * ny};
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;

@@ -19,4 +19,17 @@ for n in (64, 256, 1024):
         ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], dt, L, L, rho, nu)
         got = ops.spec_residual(*d, dt, L, L, rho, nu)
         out['n%d nu%.4f' % (n, nu)] = ['%.2e' % (np.linalg.norm(g.cpu().numpy() - r) / np.linalg.norm(r)) for g, r in zip(got, ref)]
+        fref = OP.fd_residual(*[a.astype(np.float64) for a in f], dt, L / n, L / n, rho, nu, 5)
+        ffd, _ = ops.residual_both(*d, dt, L, L, rho, nu)                      # the stencil evaluated inside the fused row pass
+        sfd = ops.fd_residual(*d, dt, L / n, L / n, rho, nu, 5)               # the standalone stencil kernel
+        out['n%d nu%.4f fd fused' % (n, nu)] = ['%.2e' % (np.linalg.norm(g.cpu().numpy() - r) / np.linalg.norm(r)) for g, r in zip(ffd, fref)]
+        out['n%d nu%.4f fd standalone' % (n, nu)] = ['%.2e' % (np.linalg.norm(g.cpu().numpy() - r) / np.linalg.norm(r)) for g, r in zip(sfd, fref)]
+    # smooth fields (Taylor-Green + band-limited noise): the case where second differences cancel hardest
+    f = residual_inputs(2, n, dt=dt, nu=1.0, rho=rho)
+    d = [torch.as_tensor(a, device='cuda') for a in f]
+    fref = OP.fd_residual(*[a.astype(np.float64) for a in f], dt, L / n, L / n, rho, 1.0, 5)
+    ffd, _ = ops.residual_both(*d, dt, L, L, rho, 1.0)
+    sfd = ops.fd_residual(*d, dt, L / n, L / n, rho, 1.0, 5)
+    out['n%d smooth nu1 fd fused' % n] = ['%.2e' % (np.linalg.norm(g.cpu().numpy() - r) / np.linalg.norm(r)) for g, r in zip(ffd, fref)]
+    out['n%d smooth nu1 fd standalone' % n] = ['%.2e' % (np.linalg.norm(g.cpu().numpy() - r) / np.linalg.norm(r)) for g, r in zip(sfd, fref)]
 print(json.dumps(out, indent=1))
