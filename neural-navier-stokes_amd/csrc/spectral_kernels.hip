@@ -304,10 +304,16 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                     constexpr int m = 8 * h + i;
                     um[i] = um_p[TPF * m]; un_[i] = un_p[TPF * m]; vm[i] = vm_p[TPF * m]; vn_[i] = vn_p[TPF * m];
                     pm[i] = pm_p[TPF * m]; pn_[i] = pn_p[TPF * m];
-                    // (p's j-1 / j+1 by lane rotates of the row, like u's and v's, keeps pf live through the stencil: 21 spilled
-                    //  registers and 0.78 -> 0.91 ms, same-box A/B in round 2 -- they are read again from cache instead)
+                    // p's j-1 / j+1 by lane rotates of the row in registers, like u's and v's (two of the eight re-read streams gone).  With the
+                    // float64 Laplacian this spilled 21 registers (0.78 -> 0.91 ms); with the float32 one it fits: 252 VGPRs, 0.765 -> 0.757 ms
+#ifndef NNS_ROWPASS_PROT
+#define NNS_ROWPASS_PROT 1
+#endif
+                    if constexpr (NNS_ROWPASS_PROT) { pl[i] = left_of<m, TPF>(pf, tidv); pr[i] = right_of<m, TPF>(pf, tidv); }
+                    else {
                     if constexpr (m == 0) pl[i] = pl0_p[0]; else pl[i] = pl_p[TPF * m];
                     if constexpr (m == 15) pr[i] = pr15_p[0]; else pr[i] = pr_p[TPF * m];
+                    }
                 });
                 if (valid) {
                     static_for<0, 8>([&](auto ic) {
