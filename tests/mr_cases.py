@@ -46,7 +46,18 @@ def cavity_problem():
     return ics, (u_bc, v_bc, p_bc)
 
 
-def rank_chorin(rank, world):
+def rank_chorin96(rank, world):
+    return rank_chorin(rank, world, 96)
+
+
+def rank_chorin98(rank, world):
+    return rank_chorin(rank, world, 98)
+
+
+def rank_chorin(rank, world, n=None):
+    global CN
+    if n is not None:
+        CN = n
     from nns.slab import SlabChorinFD
     ics, (u_bc, v_bc, p_bc) = cavity_problem()
     res = {}
