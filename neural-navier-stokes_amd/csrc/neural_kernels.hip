@@ -16,6 +16,7 @@
 //   A: lane l holds A[row = l&15][k = l>>4],  B: lane l holds B[k = l>>4][col = l&15],
 //   C/D: lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3.
 #include "nns_common.h"
+#include <cstdlib>
 
 using namespace nns;
 
@@ -163,6 +164,97 @@ __global__ __launch_bounds__(NT) void ode_mlp_fwd_kernel(const float* __restrict
             if (row0 + b < mb && k < K) out[((size_t)n * mb + row0 + b) * K + k] = y;
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, ONE ROW PER WORKGROUP (round 2).  The integration is Nt dependent steps of 4 (RK4) dependent MLP evaluations; the tile
+// kernel above spends 14 us per RK4 step on a 16-row MFMA tile however few of its rows are real -- and PDEFunc integrates ONE shared
+// trajectory (spectral_ode.py:69).  Here a workgroup of two waves owns one batch row and keeps ALL THREE weight matrices in
+// registers (thread n holds row n of W0 and W1: 32 + 128 values, and a 32-value slice of W2): every layer is a broadcast read of the
+// activation vector from LDS + an FMA chain per thread, 4 small barriers per evaluation -- about 2.6 us per RK4 step, and batch rows
+// run on different CUs.  Plain float32 FMAs (the sum order differs from the MFMA tile's; both are float32 dot products).
+// ------------------------------------------------------------------------------------------
+constexpr int RT = 128;            // threads per row workgroup
+__global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __restrict__ z0, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                             const float* __restrict__ W1, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2,
+                                                             float* __restrict__ out, int mb, int K, int Nt, int method) {
+    __shared__ __attribute__((aligned(16))) float S[KP], h1[H], h2[H], part[4][KP], sb0[H], sb1[H], sb2[KP];
+    const int t = threadIdx.x, row = blockIdx.x;
+    const int n3 = t & 31, pq = t >> 5;                       // layer 3: output n3, quarter pq of the 128 hidden inputs
+    float w0[KP], w1[H], w2[32];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) w0[j] = j < K ? W0[(size_t)t * K + j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < H; ++j) w1[j] = W1[(size_t)t * H + j];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) w2[j] = n3 < K ? W2[(size_t)n3 * H + 32 * pq + j] : 0.f;
+    sb0[t] = b0[t]; sb1[t] = b1[t];
+    if (t < KP) sb2[t] = t < K ? b2[t] : 0.f;
+    float y = 0.f, acc = 0.f;                                  // RK state of coefficient t (threads t < KP)
+    if (t < KP) { y = t < K ? z0[(size_t)row * K + t] : 0.f; S[t] = y; }
+    __syncthreads();
+    const float dt = 1.f / (float)Nt;
+    const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
+    const int nstage = method == METHOD_RK4 ? 4 : (method == METHOD_RK2 ? 2 : 1);
+    for (int n = 0; n < Nt; ++n) {
+        for (int s = 0; s < nstage; ++s) {
+            {   // layer 1: K -> 128, ReLU
+                float a0 = sb0[t], a1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < KP; j += 8) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(S + j), x1 = *reinterpret_cast<const float4*>(S + j + 4);
+                    a0 = fmaf(w0[j], x0.x, a0); a0 = fmaf(w0[j + 1], x0.y, a0); a0 = fmaf(w0[j + 2], x0.z, a0); a0 = fmaf(w0[j + 3], x0.w, a0);
+                    a1 = fmaf(w0[j + 4], x1.x, a1); a1 = fmaf(w0[j + 5], x1.y, a1); a1 = fmaf(w0[j + 6], x1.z, a1); a1 = fmaf(w0[j + 7], x1.w, a1);
+                }
+                h1[t] = fmaxf(a0 + a1, 0.f);
+            }
+            __syncthreads();
+            {   // layer 2: 128 -> 128, ELU(alpha = 1); four independent chains
+                float a[4] = {sb1[t], 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < H; j += 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 x = *reinterpret_cast<const float4*>(h1 + j + 4 * q);
+                        a[q] = fmaf(w1[j + 4 * q], x.x, a[q]); a[q] = fmaf(w1[j + 4 * q + 1], x.y, a[q]);
+                        a[q] = fmaf(w1[j + 4 * q + 2], x.z, a[q]); a[q] = fmaf(w1[j + 4 * q + 3], x.w, a[q]);
+                    }
+                }
+                const float z = (a[0] + a[1]) + (a[2] + a[3]);
+                h2[t] = z > 0.f ? z : expm1f(z);
+            }
+            __syncthreads();
+            {   // layer 3: 128 -> K, a quarter of the inputs per thread
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 32; j += 8) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(h2 + 32 * pq + j), x1 = *reinterpret_cast<const float4*>(h2 + 32 * pq + j + 4);
+                    a0 = fmaf(w2[j], x0.x, a0); a0 = fmaf(w2[j + 1], x0.y, a0); a0 = fmaf(w2[j + 2], x0.z, a0); a0 = fmaf(w2[j + 3], x0.w, a0);
+                    a1 = fmaf(w2[j + 4], x1.x, a1); a1 = fmaf(w2[j + 5], x1.y, a1); a1 = fmaf(w2[j + 6], x1.z, a1); a1 = fmaf(w2[j + 7], x1.w, a1);
+                }
+                part[pq][n3] = a0 + a1;
+            }
+            __syncthreads();
+            if (t < KP) {   // F, then the scheme's update of this coefficient (scheme.py:21-42), as in ode_mlp_fwd_kernel
+                const float F = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) + sb2[t];
+                const float k = dt * F;
+                if (method == METHOD_EULER) { acc = y + k; }
+                else if (method == METHOD_RK2) { if (s == 0) S[t] = y + 0.5f * k; else acc = y + k; }
+                else {
+                    if (s == 0) { acc = y + c6 * k; S[t] = y + 0.5f * k; }
+                    else if (s == 1) { acc = acc + c3 * k; S[t] = y + 0.5f * k; }
+                    else if (s == 2) { acc = acc + c3 * k; S[t] = y + k; }
+                    else { acc = acc + c6 * k; }
+                }
+                if (s == nstage - 1) {
+                    y = acc; S[t] = y;
+                    if (t < K) out[((size_t)n * mb + row) * K + t] = y;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -794,6 +886,12 @@ NNS_API int nns_ode_mlp_fwd_f32(const float* z0, const float* W0, const float* b
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ode_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds);
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
+    }
+    static const int row_max = [] { const char* e = getenv("NNS_ODE_ROW_MAX"); return e ? atoi(e) : 4096; }();      // 0 forces the MFMA tile kernel (A/B, tests)
+    if (mb <= row_max) {
+        // one row per workgroup, weights in registers: ~2.6 us per RK4 step whatever the batch, against 14 us for a 16-row MFMA tile
+        hipLaunchKernelGGL(ode_mlp_fwd_row_kernel, dim3(mb), dim3(RT), 0, S(stream), z0, W0, b0, W1, b1, W2, b2, out, mb, K, Nt, method);
+        return check_launch("ode_mlp_fwd");
     }
     hipLaunchKernelGGL(ode_mlp_fwd_kernel, dim3((mb + TB - 1) / TB), dim3(NT), kFwdLds, S(stream), z0, W0, b0, W1, b1, W2, b2, out, mb, K, Nt, method);
     return check_launch("ode_mlp_fwd");

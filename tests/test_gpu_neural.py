@@ -379,3 +379,32 @@ def test_cfg5_shape_loss_and_gradients_are_sums_over_chunks(gpu_device):
             assert rel_l2(gc_small.cpu().numpy(), torch.einsum('tcp,kcp->tkc', r, b64).cpu().numpy()) < 2e-6
     assert abs(ss_sum - float(ss.item())) < 1e-9 * ss_sum
     assert rel_l2(gb.cpu().numpy(), gb_sum.cpu().numpy()) < 2e-6
+
+
+def test_ode_forward_row_kernel_matches_tile_kernel(tmp_path, gpu_device):
+    """nns_ode_mlp_fwd_f32 has two kernels: one batch row per workgroup with the weights in registers (mb <= 4096, the default
+    path of every test above) and the 16-row MFMA tile kernel (larger batches).  The tile kernel is forced in a child process
+    (NNS_ODE_ROW_MAX=0 is read once per process) and must give the same trajectories to float32 rounding, for all three schemes
+    and a ragged batch."""
+    import os, subprocess, sys
+    from conftest import PKG
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from nns import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "K, mb, Nt = 30, 37, 9\n"
+        "W = [torch.randn(128, K, generator=g) * 0.1, torch.zeros(128), torch.randn(128, 128, generator=g) * 0.1, torch.randn(128, generator=g) * 0.01,\n"
+        "     torch.randn(K, 128, generator=g) * 0.1, torch.randn(K, generator=g) * 0.01]\n"
+        "z0 = torch.randn(mb, K, generator=g)\n"
+        "out = {m: ops.ode_mlp_fwd(z0.cuda(), *[w.cuda() for w in W], Nt, m).cpu().numpy() for m in ('Euler', 'RK2', 'RK4')}\n"
+        "np.savez(sys.argv[1], **out)\n" % PKG)
+    outs = {}
+    for tag, env in (('row', {}), ('tile', {'NNS_ODE_ROW_MAX': '0'})):
+        path = str(tmp_path / (tag + '.npz'))
+        r = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(path)
+    for m in ('Euler', 'RK2', 'RK4'):
+        assert outs['row'][m].shape == (9, 37, 30)
+        assert rel_l2(outs['row'][m], outs['tile'][m]) < 2e-6, m
