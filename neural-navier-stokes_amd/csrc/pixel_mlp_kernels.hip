@@ -663,6 +663,195 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same backward with SPLIT ROLES (round 2): pixel_mlp_bwd_uniform_kernel serialises, in ONE wave per SIMD (455 registers), the
+// forward recompute, the data chain, the image writes, a barrier and the pixel contraction of the weight gradients -- 4500 cycles per
+// layer and tile against 770 of MFMA.  Here a workgroup has EIGHT waves, two per SIMD, each under 256 registers:
+//   * four CHAIN waves (one 32-pixel tile each): forward recompute, data chain, delta_l / a_{l-1} images -- no weight-gradient
+//     accumulators (128 registers less);
+//   * four GRADIENT waves (one 32x32 block of every layer's gW each; OT = 1: a quarter of the pixels each): after the layer's barrier
+//     they contract the images over the 128 pixels while the chain waves are already on the next layer -- no activations kept
+//     (128 registers less).
+// Per layer still ONE workgroup barrier: the chain waves write layer l-1's images into the set the gradient waves finished reading
+// before that barrier (layer l+1's).  The two role bodies are separate code paths (separate loops with matching barriers), so that the
+// register allocator sees two small live sets instead of their union.
+// ------------------------------------------------------------------------------------------------------------------
+template <int OT, bool SMALLIO>
+__global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                   const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                   float* __restrict__ gx, float* __restrict__ ws,
+                                                                   long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
+    using U = BwdLds<OT>;
+    constexpr int SS = U::SS, ROWB = U::ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nl = d.nlayers;
+    {   // stage: zero everything (pads, images), then scatter the real matrices (coalesced reads)
+        const int total = U::total(nl);
+        for (int e = threadIdx.x; e < total / 16; e += 512) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int l = 0; l < nl; ++l) {
+            const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
+            const float* Wl = W + d.woff[l];
+            unsigned char* dst = lds + l * U::W_BYTES;
+            for (int e = threadIdx.x; e < n; e += 512) *reinterpret_cast<unsigned short*>(dst + (e / cin) * ROWB + (e % cin) * 2) = f2bf(Wl[e]);
+            float* bl = reinterpret_cast<float*>(lds + nl * U::W_BYTES + l * U::B_BYTES);
+            for (int e = threadIdx.x; e < cout; e += 512) bl[e] = Bv[d.boff[l] + e];
+        }
+        __syncthreads();
+    }
+    const unsigned char* bias0 = lds + nl * U::W_BYTES;
+    unsigned char* img0 = lds + nl * (U::W_BYTES + U::B_BYTES);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
+    const long nsuper = (npix_total + 127) / 128;
+    if (wave >= 4) {
+        // ================= gradient waves =================
+        const int gwv = wave - 4;
+        const int bo = OT == 2 ? gwv >> 1 : 0, bi = OT == 2 ? gwv & 1 : 0;     // this wave's gW block
+        constexpr int KS = OT == 2 ? 8 : 2;                                     // its k-steps (of 8 x 16 pixels)
+        const int ks0 = OT == 2 ? 0 : 2 * gwv;
+        const bool do_gb = OT == 2 ? bi == 0 : true;
+        f32x16 gw[kMaxLayers];
+        float gbp[kMaxLayers];
+#pragma unroll
+        for (int l = 0; l < kMaxLayers; ++l) {
+            gbp[l] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gw[l][i] = 0.f;
+        }
+        for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+#pragma unroll
+            for (int l = kMaxLayers - 1; l >= 0; --l) {
+                if (l < nl) {
+                    const unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
+                    const unsigned char* imgA = imgD + U::IMG_BYTES;
+                    __syncthreads();                                            // layer l's images are written
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) {
+                        const bf16x8 fa = frag_pix<ROWB>(imgD, lane, ks0 + kk, 32 * bo);
+                        const bf16x8 fb = frag_pix<ROWB>(imgA, lane, ks0 + kk, 32 * bi);
+                        gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                        if (kk & 1) __builtin_amdgcn_sched_barrier(0);
+                        if (do_gb) {
+                            const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+                            for (int j = 0; j < 8; j += 2) {
+                                const unsigned pr = (unsigned)(unsigned short)fa[j] | ((unsigned)(unsigned short)fa[j + 1] << 16);
+                                gbp[l] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pr), ones, gbp[l], false);
+                            }
+                        }
+                    }
+                }
+            }
+            if (nl & 1) __syncthreads();                                        // end of the super-tile: see the chain waves
+        }
+        float* wsb = ws + (size_t)(OT == 2 ? blockIdx.x : blockIdx.x * 4 + gwv) * nparams;
+#pragma unroll
+        for (int l = 0; l < kMaxLayers; ++l) {
+            if (l < nl) {
+                const int cin = d.cin[l], cout = d.cout[l];
+                const int in = 32 * bi + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int out = 32 * bo + acc_row(i, h);
+                    if (out < cout && in < cin) wsb[d.woff[l] + out * cin + in] = gw[l][i];
+                }
+                if (do_gb) {
+                    const float tot = gbp[l] + __shfl_xor(gbp[l], 32);
+                    if (h == 0 && 32 * bo + r < cout) wsb[nparams_w + d.boff[l] + 32 * bo + r] = tot;
+                }
+            }
+        }
+        return;
+    }
+    // ================= chain waves =================
+    const int cin0 = d.cin[0], coutL = d.cout[nl - 1];
+    for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+        const long gp = sup * 128 + wave * 32 + r;
+        const bool ok = gp < npix_total;
+        const long gc = ok ? gp : npix_total - 1;
+        const long b = gc / P, p = gc % P;
+        // ---------------- forward: afrag[l] = input fragments of layer l
+        bf16x8 afrag[kMaxLayers][SS];
+        load_frags<SS, SMALLIO>(x + (size_t)b * cin0 * P + p, (size_t)P, cin0, ok, h, afrag[0]);
+#pragma unroll
+        for (int l = 0; l + 1 < kMaxLayers; ++l) {
+            if (l + 1 < nl) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wimg = lds + l * U::W_BYTES;
+                const float* bl = reinterpret_cast<const float*>(bias0 + l * U::B_BYTES);
+                f32x16 acc[OT];
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ot][i] = bl[32 * ot + acc_row(i, h)];
+#pragma unroll
+                    for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<ROWB>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
+                }
+                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < SS; ++s) {
+                    bf16x8 t;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(acc[s >> 1][8 * (s & 1) + j]);
+                    afrag[l + 1][s] = __builtin_elementwise_max(t, zero);
+                }
+            }
+        }
+        // ---------------- backward
+        bf16x8 dfrag[SS];
+        {
+            f32x16 dl[OT];
+            load_acc<OT, SMALLIO>(gy + (size_t)b * coutL * P + p, (size_t)P, coutL, ok, h, dl);
+#pragma unroll
+            for (int s = 0; s < SS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dfrag[s][j] = (short)f2bf(dl[s >> 1][8 * (s & 1) + j]);
+        }
+#pragma unroll
+        for (int l = kMaxLayers - 1; l >= 0; --l) {
+            if (l < nl) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wimg = lds + l * U::W_BYTES;
+                f32x16 nd[OT];
+#pragma unroll
+                for (int it = 0; it < OT; ++it) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < SS; ++s) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<ROWB>(wimg, lane, s, 32 * it), dfrag[s], nd[it], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
+                unsigned char* imgA = imgD + U::IMG_BYTES;
+                {
+                    unsigned char* rowD = imgD + (32 * wave + r) * ROWB;
+                    unsigned char* rowA = imgA + (32 * wave + r) * ROWB;
+#pragma unroll
+                    for (int s = 0; s < SS; ++s) {
+                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
+                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
+                    }
+                }
+                __syncthreads();                                                // layer l's images are written: over to the gradient waves
+                if (l > 0) {
+#pragma unroll
+                    for (int s = 0; s < SS; ++s)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dfrag[s][j] = afrag[l][s][j] != 0 ? (short)f2bf(nd[s >> 1][8 * (s & 1) + j]) : (short)0;
+                } else if (ok) {
+                    store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
+                }
+            }
+        }
+        // With an EVEN number of layers the next super-tile's first images (layer nl-1, odd set) never meet the set layer 0 is still being
+        // read from (even), and its second ones are written after a barrier the gradient waves only reach once they are done with layer 0:
+        // no barrier between super-tiles, the chain waves run ahead into the next forward recompute.  Odd nl: both layers share a set.
+        if (nl & 1) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // float32-operand backward (widths <= 32: e.g. BASELINE config 2's depth-4 width-32 stack), v_mfma_f32_32x32x2_f32.
 // Same structure as the bf16 kernel with OT = 1, but nothing is rounded: the accumulator registers ARE the next
 // product's B operand (k-step i of a 32x32x2 MFMA takes channels {c(i), c(i) + 4}, c(i) = (i&3) + 8 (i>>2), i.e. exactly
@@ -853,6 +1042,14 @@ int launch_bwd_uniform(const float* x, const float* gy, const float* weights, co
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
     const long nsuper = (npix + 127) / 128;
     const int blocks = (int)(nsuper < kBwdMaxBlocks ? nsuper : kBwdMaxBlocks);
+#ifndef NNS_PM_SPLIT
+#define NNS_PM_SPLIT 1             // 1: pixel_mlp_bwd_split_kernel (4 chain waves + 4 gradient waves), 0: pixel_mlp_bwd_uniform_kernel
+#endif
+    if (NNS_PM_SPLIT && BwdLds<OT>::total(d.nlayers) == lds && NNS_PM_IMGSETS == 2) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_split_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+        hipLaunchKernelGGL((pixel_mlp_bwd_split_kernel<OT, SMALLIO>), dim3(blocks), dim3(512), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
+    } else
     hipLaunchKernelGGL((pixel_mlp_bwd_uniform_kernel<OT, SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
     if (int rc = check_launch("pixel_mlp_bwd")) return rc;
     const int nslices = blocks * (OT == 2 ? 1 : 4);
