@@ -396,3 +396,19 @@ def test_fused_both_residuals(nx, ny, batch, gpu_device):
     assert all(rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6 for a, b in zip(e_fd, s_fd))
     with pytest.raises(RuntimeError):
         ops.residual_both(*[t[:, :, :48].contiguous() for t in d], DT, Lx, Ly, RHO, NU)        # not a power of two: loud, no silent fallback
+
+
+@pytest.mark.parametrize('nx,ny', [(64, 52), (128, 20), (1024, 12), (256, 8)])
+def test_column_pass_ragged_column_counts(nx, ny, gpu_device):
+    """The column pass needs nx to be a power of two but takes ANY number of columns (a column slab of a sharded grid, nns.slab):
+    tiles of 8 * (1024 / nx) columns with a ragged last tile (masked stores, clamped loads), fewer columns than one tile, and the
+    role-split kernel's memory waves on a partly filled tile -- against oracle.periodic.spectral_xpart."""
+    from nns import ops
+    from oracle import periodic as OP
+    rng = np.random.default_rng(nx * 1000 + ny)
+    f = [rng.standard_normal((3, nx, ny)).astype(np.float32) for _ in range(3)]
+    Lx, rho, nu = 2.5, 1.3, 0.05
+    got = ops.spec_residual_xpass(*[dev(a) for a in f], Lx, rho, nu)
+    ref = OP.spectral_xpart(*[a.astype(np.float64) for a in f], Lx, rho, nu)
+    for g, r in zip(got, ref):
+        assert g.shape == (3, nx, ny) and rel_l2(g.cpu().numpy(), r) <= TOL
