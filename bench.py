@@ -72,14 +72,20 @@ def time_kernel(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_baseline(n, budget_s=20.0):
+def cpu_baseline(n, budget_s=20.0, check=None):
     """The NumPy oracle (float64) on this host: FD 5-point + spectral residual of single 1024^2 grids,
-    repeated until ~budget_s of CPU time."""
+    repeated until ~budget_s of CPU time.  check: the timed step's six output fields of grid 0 (the same inputs): their rel-L2
+    distance from the oracle is reported as cpu_baseline.oracle_check (the oracle as the checker of the measured path)."""
     from oracle import periodic as OP
     from nns.synthetic import residual_inputs
     f = [a[0].astype(np.float64) for a in residual_inputs(1, n)]
     dt, nu, rho, L = 1e-3, 2 * np.pi / 1000, 1.0, 2 * np.pi
     h = L / n
+    oracle_check = None
+    if check is not None:
+        ref = list(OP.fd_residual(*f, dt, h, h, rho, nu, 5)) + list(OP.spectral_residual(*f, dt, L, L, rho, nu))
+        rl = [float(np.linalg.norm(g - r) / np.linalg.norm(r)) for g, r in zip(check, ref)]
+        oracle_check = dict(fd_rel_l2=rl[:3], spectral_rel_l2=rl[3:], tolerance=1e-5, grid='grid 0 of the timed batch, outputs of the last timed step')
     t0 = time.perf_counter()
     reps = 0
     while True:
@@ -91,7 +97,7 @@ def cpu_baseline(n, budget_s=20.0):
             break
     return dict(value=reps * n * n / el, unit='residual-updates/s', cores=1, kind='port',
                 sample='%d x (FD 5-point + rfft2 spectral residual) of one %dx%d float64 grid, NumPy oracle, %.1f s'
-                       % (reps, n, n, el), host_cores_present=os.cpu_count())
+                       % (reps, n, n, el), host_cores_present=os.cpu_count(), oracle_check=oracle_check)
 
 
 def _cpu_worker(arg):
@@ -132,7 +138,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--distinct', type=int, default=8, help='distinct synthetic grids generated on the host (tiled to --batch)')
     ap.add_argument('--stencil', type=int, default=5)
-    ap.add_argument('--fast', action='store_true', help='all-float32 spectral path (2e-4 rel-L2) instead of the precise one')
+    ap.add_argument('--fast', action='store_true', help='precise=0: all-float32 transforms whatever the viscosity')
+    ap.add_argument('--f64', action='store_true', help='precise=2: float64 forward transforms always (the default, precise=1, lets the library take the '
+                                                        'all-float32 differenced mode when its error bound allows: it does at this configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--separate', action='store_true',
                     help='launch the FD and the spectral residual separately (3 launches) instead of the fused row pass (2 launches)')
@@ -175,18 +183,19 @@ def main():
     from nns import ops, _lib
     from nns.periodic import ResidualEngine
     n, B = args.n, args.batch
+    prec = 0 if args.fast else (2 if args.f64 else 1)
     dt, nu, rho, L = 1e-3, 2 * np.pi / 1000, 1.0, 2 * np.pi
     if rank == 0:
         log('bench: device', _lib.device_info(), 'world', world)
         log('bench: generating %d distinct %dx%d grids on the host ...' % (min(args.distinct, B), n, n))
     slab = args.mode == 'slab' and world > 1
     f = make_inputs(B, n, args.distinct, 1234 + (0 if slab else 1000 * rank), device)
-    eng = ResidualEngine(n, n, dt, rho, nu, L, L, backend='spectral', precise=not args.fast)
+    eng = ResidualEngine(n, n, dt, rho, nu, L, L, backend='spectral', precise=prec)
     if slab:
         from nns.slab import SlabResidual
         nloc = n // world
         f = [t[:, rank * nloc:(rank + 1) * nloc].contiguous() for t in f]          # this rank's rows of every grid
-        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=not args.fast)
+        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=prec)
 
         def step():           # halo exchange under the two transposes + column pass, then ONE fused row pass (5-point stencil)
             sl.both(*f, stencil=args.stencil)
@@ -216,6 +225,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # grid 0 of the timed step's outputs, for the oracle check next to the CPU baseline (the per-kernel timing below reuses the buffers)
+    check_out = [t[0].cpu().numpy() for t in (*out_fd, *out_sp)] if (rank == 0 and not slab and world == 1 and not args.no_cpu_baseline and args.stencil == 5) else None
     pts = float(B) * n * n
     value = (1 if slab else world) * pts * args.steps / elapsed          # slab: the ranks share ONE batch of grids
 
@@ -230,13 +241,13 @@ def main():
         fused = (not slab) and (not args.separate) and args.stencil == 5
         standalone = {
             'fd_residual': time_kernel(lambda: eng.fd(*f, stencil=args.stencil, out=out_fd), iters),
-            'spec_xpass': time_kernel(lambda: ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, not args.fast, out=out_sp), iters),
-            'spec_ypass': time_kernel(lambda: ops.spec_residual_ypass_(*f, *out_sp, dt, L, rho, nu, not args.fast), iters),
+            'spec_xpass': time_kernel(lambda: ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, prec, out=out_sp), iters),
+            'spec_ypass': time_kernel(lambda: ops.spec_residual_ypass_(*f, *out_sp, dt, L, rho, nu, prec), iters),
         }
         if fused:                              # the launches the timed step is made of
-            ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, not args.fast, out=out_sp)
+            ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, prec, out=out_sp)
             kt = {'spec_xpass': standalone['spec_xpass'],
-                  'both_rowpass': time_kernel(lambda: ops.residual_both(*f, dt, L, L, rho, nu, not args.fast, out_fd=out_fd, out_spec=out_sp,
+                  'both_rowpass': time_kernel(lambda: ops.residual_both(*f, dt, L, L, rho, nu, prec, out_fd=out_fd, out_spec=out_sp,
                                                                          rowpass_only=True), iters)}
         else:
             kt = dict(standalone)
@@ -275,7 +286,10 @@ def main():
                                   'tests hold the kernels to 1e-5 rel-L2 of that float64 oracle',
                       value=value, unit='residual-updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong' if slab else 'weak', vs_baseline=None,
-                      dtype='f32' if args.fast else 'f32 fields; f64 forward FFT + f32 inverse FFT; f32 stencil',
+                      dtype='f32' if prec < 2 else 'f32 fields; f64 forward FFT + f32 inverse FFT; f32 stencil',
+                      precision=dict(precise=prec, note='precise=1: the library takes all-float32 transforms on forward-differenced lines while the viscous '
+                                     'amplification nu pi N/(sqrt(3) L) <= 8 (1.86 here), float64 forward transforms otherwise; rel-L2 against the float64 '
+                                     'oracle in cpu_baseline.oracle_check'),
                       data='synthetic',
                       config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral%s'
                                            % (n, n, B, args.stencil, ' (fused row pass: 2 launches)' if fused else ' (separate launches)'),
@@ -287,7 +301,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             log('bench: timing the NumPy oracle on the host (bounded sample) ...')
-            result['cpu_baseline'] = cpu_baseline(n)
+            result['cpu_baseline'] = cpu_baseline(n, check=check_out)
             result['cpu_baseline']['all_cores'] = all_cores        # extra row: one oracle process per usable host core
         else:
             result['cpu_baseline'] = None

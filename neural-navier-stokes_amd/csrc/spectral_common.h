@@ -37,8 +37,9 @@ struct SpecLds {
     static constexpr int LINE_BYTES = ((XB_BYTES > STAGE_BYTES ? XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
     static constexpr int TABF_BYTES = (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<TF>);     // main half table + pass-2 table
     // float32 tables of the precise mode + the pressure filter table ctab[k] = k_odd cot(pi k / N), k = 0 .. N/2 (deriv_core)
-    static constexpr int CTAB_BYTES = sizeof(TF) == 4 ? 0 : ((N / 2 + 1) * 4 + 15) / 16 * 16;
-    static constexpr int TABI_BYTES = sizeof(TF) == 4 ? 0 : (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<float>) + CTAB_BYTES;
+    // (all-float32 mode: the float32 tables ARE tabF, only ctab follows them)
+    static constexpr int CTAB_BYTES = ((N / 2 + 1) * 4 + 15) / 16 * 16;
+    static constexpr int TABI_BYTES = (sizeof(TF) == 4 ? 0 : (N / 2 + Pass2<N>::ENTRIES) * (int)sizeof(C2<float>)) + CTAB_BYTES;
     static constexpr int TOTAL = TABF_BYTES + TABI_BYTES + LINES * LINE_BYTES;
 };
 
@@ -64,6 +65,8 @@ __device__ __forceinline__ void spec_setup(unsigned char* smem, C2<TF>*& tabF, C
         tabI = reinterpret_cast<C2<float>*>(smem + L::TABF_BYTES);
         fill_twiddles<float, N>(tabI, threadIdx.x, NTHREADS);
         fill_twiddles2<float, N>(tabI + N / 2, threadIdx.x, NTHREADS);
+    }
+    {
         float* ctab = reinterpret_cast<float*>(tabI + N / 2 + Pass2<N>::ENTRIES);
         for (int kk = threadIdx.x; kk <= N / 2; kk += NTHREADS) {
             double sn, cs;

@@ -89,7 +89,11 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
 #ifndef NNS_P32
 #define NNS_P32 1          // 1: the pressure transform in float32 on the forward-DIFFERENCED line (precise mode); 0: float64 FFT(p)
 #endif
-    if constexpr (sizeof(TF) == 8 && NNS_P32) {
+#ifndef NNS_F32_DIFF
+#define NNS_F32_DIFF 1     // 1: the all-float32 mode transforms forward DIFFERENCES of u, v, p (bounded filters, see below); 0: the fields themselves
+#endif
+    constexpr bool DIFF32 = sizeof(TF) == 4 && NNS_F32_DIFF;
+    if constexpr ((sizeof(TF) == 8 && NNS_P32) || DIFF32) {
         // p enters the residual only through its FIRST derivative.  FFT(p) in float32 would not do: its rounding noise, white
         // in k, is amplified by k (4e-5 of |p| at N = 1024).  The forward difference d_j = p_{j+1} - p_j (exact or correctly
         // rounded in float32) has FFT(d) = (e^{i theta} - 1) FFT(p), so
@@ -134,6 +138,36 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
     });
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIFF32) {
+        // ---- velocity, all-float32: D = FFT(d), d_j = (u + i v)_{j+1} - (u + i v)_j, so that  FFT(u + i v) = D / (e^{i theta} - 1)  and
+        //     i k   FFT(u + i v) = M1 D,   M1 = (k / 2) (cot(theta / 2) - i)                       (bounded: no noise amplification)
+        //     nu k^2 FFT(u + i v) = F2 D,  F2 = -(nu k / 2) (k + i k cot(theta / 2))  = -i nu k M1  (amplification nu k relative to M1)
+        // The differences remove the large smooth part of the fields before the float32 transform: its white rounding noise is then
+        // relative to |d| ~ h |u_x| instead of |u|, and the first derivatives come out at float32 accuracy.  The viscous term keeps an
+        // amplification of nu |k| relative to the first derivatives (rms nu pi N / (sqrt(3) L)); the host picks this mode for a
+        // `precise` request only while that factor is small (spec_precise_in_f32), and the float64 forward transform otherwise.
+        C2<float> zv[16];
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            zv[m].x = right_of<m, N / 16>(uf, tid) - uf[m];
+            zv[m].y = right_of<m, N / 16>(vf, tid) - vf[m];
+        });
+        fft_line<float, N, false, P>(zv, tabI, tabI2, xbI, tid, hook);
+        int te = tid;
+        asm volatile("" : "+v"(te), "+v"(zv[0].x));
+        const float c1h = (float)(0.5 * k.c1), c2h = (float)(0.5 * k.c2);
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            int ko, ke;
+            wavenumber<N, m>(te, ko, ke);
+            const float ct = ctab[ke < 0 ? -ke : ke];                        // k cot(pi k / N), even in k, 0 at k = 0 and at the Nyquist mode
+            const float ar = ct * c1h, ai = (float)ko * c1h;                 // M1 = ar - i ai
+            a[m].x = ar * zv[m].x + ai * zv[m].y; a[m].y = ar * zv[m].y - ai * zv[m].x;
+            const float kf = (float)ke * c2h;
+            const float br = kf * (float)ke, bi = kf * ct;                   // F2 = -(br + i bi)
+            b[m].x -= br * zv[m].x - bi * zv[m].y; b[m].y -= br * zv[m].y + bi * zv[m].x;
+        });
+    } else {
     // ---- velocity: Z1 = FFT(u + i v)
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)uf[m]; z[m].y = (TF)vf[m]; }
@@ -149,6 +183,7 @@ __device__ __forceinline__ void deriv_core(const float (&uf)[16], const float (&
         a[m].x = (float)(-k1 * z[m].y); a[m].y = (float)(k1 * z[m].x);        // i k Z1
         b[m].x += (float)(k2 * z[m].x); b[m].y += (float)(k2 * z[m].y);       // nu k^2 Z1
     });
+    }
     // ---- inverse transforms in float32
     __builtin_amdgcn_sched_barrier(0);
     fft_line<float, N, true, 2 * P>(a, tabI, tabI2, xbI, tid, hook);
@@ -288,8 +323,14 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
             const size_t bm = (size_t)(gi * nx + (ii == 0 ? nx - 1 : ii - 1)) * N + tidv;       // rows i-1, i+1 (periodic in the grid), i
             const size_t bp = (size_t)(gi * nx + (ii == nx - 1 ? 0 : ii + 1)) * N + tidv;
             const size_t bc = (size_t)row * N;
+#ifdef NNS_ROWPASS_EXP              // timing experiment (wrong results): the stencil's rows i-1 / i+1 read from row i (no second touch of other rows)
+            const float* um_p = u + bc + tidv; const float* un_p = um_p; const float* vm_p = v + bc + tidv; const float* vn_p = vm_p;
+            const float* pm_p = p + bc + tidv; const float* pn_p = pm_p;
+            (void)bm; (void)bp;
+#else
             const float* um_p = u + bm; const float* un_p = u + bp; const float* vm_p = v + bm; const float* vn_p = v + bp;
             const float* pm_p = p + bm; const float* pn_p = p + bp;
+#endif
             if (hk.top && ii == 0) { const float* h = hk.top + (size_t)gi * N + tidv; um_p = h; vm_p = h + hk.fstride; pm_p = h + 2 * hk.fstride; }
             if (hk.bot && ii == nx - 1) { const float* h = hk.bot + (size_t)gi * N + tidv; un_p = h; vn_p = h + hk.fstride; pn_p = h + 2 * hk.fstride; }
             const float* pl_p = p + bc + tidv - 1;                          // column - 1: wraps only for column 0 (slot 0 of lane 0)
@@ -347,6 +388,180 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                     });
                 }
             });
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused row pass, MARCHING form (all-float32 mode).  spec_ypass_kernel<N, TF, true> hands a workgroup eight consecutive rows per
+// iteration and re-reads the stencil's rows i-1 / i+1 of u, v, p from memory one and a half iterations after they were first
+// touched -- by then they have left the 4 MB L2 of the XCD (its contents turn over every ~5 us), so six of the pass's twenty
+// streams are fetched twice (measured 1.31x the algorithmic bytes).  Here every LINE walks down its own chunk of R consecutive rows
+// of one grid: the row below is the next row's prefetch, which the pass issues anyway, and the row above is the row the line has
+// just finished -- u and v parked in a lane-private LDS image behind the exchange buffer (the all-float32 mode leaves the room:
+// 8.5 + 8 KB per line), p in 16 registers.  The stencil phase then issues no global load at all; per chunk two extra rows are read
+// (2 / R of three streams).  Lines are independent, no workgroup barrier anywhere, as before.
+// ------------------------------------------------------------------------------------------
+template <int N>
+struct MarchLds {
+    using L = SpecLds<N, float>;
+    static constexpr int XB = (L::XB_BYTES + 127) / 128 * 128;
+    static constexpr int PARK = 2 * N * 4;                          // u, v of the row above: float4 [8][TPF], lane-private
+    static constexpr int LINE_BYTES = XB + PARK;
+    static constexpr int TOTAL = L::TABF_BYTES + L::TABI_BYTES + L::LINES * LINE_BYTES;
+};
+template <int N>
+__global__ __launch_bounds__(kSpecThreads) void spec_rowmarch_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                                      const float* __restrict__ p, const float* __restrict__ up,
+                                                                      const float* __restrict__ vp, float* __restrict__ ru,
+                                                                      float* __restrict__ rv, float* __restrict__ rd,
+                                                                      float* __restrict__ fu, float* __restrict__ fv, float* __restrict__ fd,
+                                                                      int nx, FdK fk, SpecK k, HaloK hk, int R, int chunks_per_grid, long nchunks) {
+    using L = SpecLds<N, float>;
+    using ML = MarchLds<N>;
+    constexpr int TPF = L::TPF;
+    static_assert(ML::TOTAL <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    C2<float>* tabF; C2<float>* tabI; unsigned char* lines;
+    spec_setup<N, float>(smem, tabF, tabI, lines);
+    const long TL = (long)gridDim.x * L::LINES;
+    const long njt = (nchunks + TL - 1) / TL;
+    for (long j = 0; j < njt; ++j) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int wave = tx / kWave, lane = tx % kWave;
+        const int sub = lane / TPF, tid = lane % TPF;
+        const int line = wave * L::FPW + sub;
+        unsigned char* xb = lines + (size_t)line * ML::LINE_BYTES;
+        float4* park = reinterpret_cast<float4*>(xb + ML::XB) + tid;           // [q] at park[q * TPF]: q = 0..3 u, 4..7 v (slots 4 q' .. 4 q' + 3)
+        const long c_raw = (long)blockIdx.x * L::LINES + line + j * TL;
+        const bool active = c_raw < nchunks;
+        const long c = active ? c_raw : nchunks - 1;
+        const long g = c / chunks_per_grid;
+        const int r0 = (int)(c % chunks_per_grid) * R;
+        const int len = active ? (nx - r0 < R ? nx - r0 : R) : 0;
+        const size_t gbase = (size_t)g * nx * N + tid;
+        // u, v, p pointers of row ii of this grid (lane's first column included); ii = -1 / nx: the periodic wrap or the neighbour rank's edge row
+        auto row_ptrs = [&](int ii, const float*& a, const float*& b, const float*& cq) {
+            const int iw = ii < 0 ? nx - 1 : (ii >= nx ? 0 : ii);
+            const size_t o = gbase + (size_t)iw * N;
+            a = u + o; b = v + o; cq = p + o;
+            if (hk.top && ii < 0) { const float* h = hk.top + (size_t)g * N + tid; a = h; b = h + hk.fstride; cq = h + 2 * hk.fstride; }
+            if (hk.bot && ii >= nx) { const float* h = hk.bot + (size_t)g * N + tid; a = h; b = h + hk.fstride; cq = h + 2 * hk.fstride; }
+        };
+        float nu[16], nv[16], np[16], pm[16];
+        {   // chunk prologue: the row above the chunk (parked) and the chunk's first row (as the "next" row)
+            const float *a, *b, *cq;
+            row_ptrs(r0 - 1, a, b, cq);
+            float t0[16], t1[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { t0[m] = a[TPF * m]; t1[m] = b[TPF * m]; pm[m] = cq[TPF * m]; }
+            row_ptrs(r0, a, b, cq);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { nu[m] = a[TPF * m]; nv[m] = b[TPF * m]; np[m] = cq[TPF * m]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                park[q * TPF] = make_float4(t0[4 * q], t0[4 * q + 1], t0[4 * q + 2], t0[4 * q + 3]);
+                park[(4 + q) * TPF] = make_float4(t1[4 * q], t1[4 * q + 1], t1[4 * q + 2], t1[4 * q + 3]);
+            }
+        }
+        for (int r = 0; r < R; ++r) {
+            const bool valid = r < len;
+            const int ii = r0 + (valid ? r : (len > 0 ? len - 1 : 0));
+            int tidv = tid;
+            asm volatile("" : "+v"(tidv));
+            float uf[16], vf[16], pf[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { uf[m] = nu[m]; vf[m] = nv[m]; pf[m] = np[m]; }
+            const float *na, *nb, *nc;
+            row_ptrs(ii + 1, na, nb, nc);
+            auto hook = [&](auto sc) {
+                if constexpr (decltype(sc)::value == 2 * FftPasses<N>::value - 1) {          // after the last forward pass: the row below
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) { nu[m] = na[TPF * m]; nv[m] = nb[TPF * m]; np[m] = nc[TPF * m]; }
+                }
+            };
+            C2<float> a[16], b[16];
+            deriv_core<N, float, false>(uf, vf, pf, a, b, tabF, tabI, xb, tidv, k, hook);
+            // p of this row and of the row above are needed by the stencil only: over the epilogue (the register peak of the iteration) they
+            // wait in the exchange image, which is idle until the next row's transforms
+            float4* pk2 = reinterpret_cast<float4*>(xb) + tidv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pk2[q * TPF] = make_float4(pf[4 * q], pf[4 * q + 1], pf[4 * q + 2], pf[4 * q + 3]);
+                pk2[(4 + q) * TPF] = make_float4(pm[4 * q], pm[4 * q + 1], pm[4 * q + 2], pm[4 * q + 3]);
+            }
+            const size_t base = gbase + (size_t)ii * N;
+            float tu[16], tv[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float pu[8], pv[8], pd[8], qu[8], qv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const size_t c2 = base + TPF * (8 * h + i);
+                    pu[i] = ld_stream<NNS_YPASS_NT>(ru + c2); pv[i] = ld_stream<NNS_YPASS_NT>(rv + c2); pd[i] = ld_stream<NNS_YPASS_NT>(rd + c2);
+                    qu[i] = ld_stream<NNS_YPASS_NT>(up + c2); qv[i] = ld_stream<NNS_YPASS_NT>(vp + c2);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = 8 * h + i;
+                    tu[m] = __fmul_rn(uf[m] - qu[i], k.inv_dt); tv[m] = __fmul_rn(vf[m] - qv[i], k.inv_dt);
+                }
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = 8 * h + i;
+                        const size_t c2 = base + TPF * m;
+                        st_stream<NNS_YPASS_NT>(ru + c2, __fadd_rn(__fmaf_rn(vf[m], a[m].x, __fadd_rn(tu[m], pu[i])), b[m].x));
+                        st_stream<NNS_YPASS_NT>(rv + c2, __fadd_rn(__fmaf_rn(vf[m], a[m].y, __fadd_rn(tv[m], pv[i])), b[m].y));
+                        st_stream<NNS_YPASS_NT>(rd + c2, pd[i] + a[m].y);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the stencil: row i-1 from the park image / pm, row i+1 = the prefetched next row, columns j-1 / j+1 by lane rotates
+            {
+                int tq = tid;
+                asm volatile("" : "+v"(tq));                                    // a different address to the compiler: no store-to-load forwarding across the epilogue
+                const float4* rk = reinterpret_cast<const float4*>(xb) + tq;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 x = rk[q * TPF], y = rk[(4 + q) * TPF];
+                    pf[4 * q] = x.x; pf[4 * q + 1] = x.y; pf[4 * q + 2] = x.z; pf[4 * q + 3] = x.w;
+                    pm[4 * q] = y.x; pm[4 * q + 1] = y.y; pm[4 * q + 2] = y.z; pm[4 * q + 3] = y.w;
+                }
+            }
+            static_for<0, 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                const float4 u0 = park[(2 * h) * TPF], u1 = park[(2 * h + 1) * TPF], v0 = park[(4 + 2 * h) * TPF], v1 = park[(5 + 2 * h) * TPF];
+                const float um[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                const float vm[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (valid) static_for<0, 8>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int m = 8 * h + i;
+                    const size_t c2 = base + TPF * m;
+                    const float ucc = uf[m], vcc = vf[m];
+                    const float ul = left_of<m, TPF>(uf, tidv), ur = right_of<m, TPF>(uf, tidv);
+                    const float vl = left_of<m, TPF>(vf, tidv), vr = right_of<m, TPF>(vf, tidv);
+                    const float pl = left_of<m, TPF>(pf, tidv), pr = right_of<m, TPF>(pf, tidv);
+                    const float ux = (nu[m] - um[i]) * fk.inv_2dx, uy = (ur - ul) * fk.inv_2dy;
+                    const float vx = (nv[m] - vm[i]) * fk.inv_2dx, vy = (vr - vl) * fk.inv_2dy;
+                    const float px = (np[m] - pm[m]) * fk.inv_2dx, py = (pr - pl) * fk.inv_2dy;
+                    const float lu = ((nu[m] - ucc) - (ucc - um[i])) * fk.inv_dx2f + ((ur - ucc) - (ucc - ul)) * fk.inv_dy2f;
+                    const float lv = ((nv[m] - vcc) - (vcc - vm[i])) * fk.inv_dx2f + ((vr - vcc) - (vcc - vl)) * fk.inv_dy2f;
+                    st_stream<NNS_YPASS_NT>(fu + c2, tu[m] + ucc * ux + vcc * uy + px * fk.inv_rho - fk.nu * lu);
+                    st_stream<NNS_YPASS_NT>(fv + c2, tv[m] + ucc * vx + vcc * vy + py * fk.inv_rho - fk.nu * lv);
+                    st_stream<NNS_YPASS_NT>(fd + c2, ux + vy);
+                });
+            });
+            // this row becomes the row above
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                park[q * TPF] = make_float4(uf[4 * q], uf[4 * q + 1], uf[4 * q + 2], uf[4 * q + 3]);
+                park[(4 + q) * TPF] = make_float4(vf[4 * q], vf[4 * q + 1], vf[4 * q + 2], vf[4 * q + 3]);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) pm[m] = pf[m];
         }
     }
 }
@@ -723,6 +938,57 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
     return check_launch("spec_residual_ypass");
 }
 
+// Which arithmetic a `precise` request gets.  The all-float32 mode (deriv_core, DIFF32) computes first derivatives at float32 accuracy
+// for any input; its viscous term carries an amplification of nu |k| relative to them, rms nu pi N / (sqrt(3) L) over the spectrum
+// (1.9 at the headline configuration: 1.1e-6 rel-L2 against the float64 oracle, 4e-6 worst case over nu <= 1 on resolved fields;
+// tools/spec_accuracy_f32.py, profiles/r02_accuracy_f32diff.json).  precise = 1 takes it while that factor is <= 8 and the float64
+// forward transform otherwise; precise = 0 always, precise >= 2 never (NNS_SPEC_F64=1 in the environment: as precise = 2).
+constexpr double kF32AmpMax = 8.0;
+inline bool spec_f32_mode(int precise, double nu, int n, double len) {
+    if (!precise) return true;
+    static const bool force64 = [] { const char* e = getenv("NNS_SPEC_F64"); return e && atoi(e) != 0; }();
+    if (precise >= 2 || force64) return false;
+    return std::fabs(nu) * M_PI * n / (1.7320508075688772 * std::fabs(len)) <= kF32AmpMax;
+}
+
+inline int device_cus() {
+    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256; return v; }();
+    return n;
+}
+#ifndef NNS_ROWMARCH
+#define NNS_ROWMARCH 1             // 1: the all-float32 fused row pass marches (spec_rowmarch_kernel); 0: spec_ypass_kernel<N, float, true>
+#endif
+// rows per chunk of the marching row pass: one chunk per line once every CU is busy, a power of two in [1, 64].  Small batches get
+// short chunks (R = 1: three row reads per row, as the non-marching kernel, but those fit the caches); the SAME kernel serves every
+// batch size, so grid b of a large batch equals the same grid evaluated alone bit for bit.
+template <int N>
+int march_chunk_rows(long nrows, int nx) {
+    const long tl = (long)device_cus() * SpecLds<N, float>::LINES;
+    const long r = nrows / tl;
+    int R = 1;
+    while (R * 2 <= r && R < 64) R *= 2;
+    while (R > nx) R /= 2;
+    return R;
+}
+template <int N>
+int launch_rowmarch(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
+                    float* fu, float* fv, float* fd, int batch, int nx, int R, const SpecK& k, const FdK& fk, const HaloK& hk, hipStream_t s) {
+    using ML = MarchLds<N>;
+    auto kern = spec_rowmarch_kernel<N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ML::TOTAL);
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec rowmarch: hipFuncSetAttribute(%d B): %s", ML::TOTAL, hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int chunks_per_grid = (nx + R - 1) / R;
+    const long nchunks = (long)batch * chunks_per_grid;
+    const long wgs = (nchunks + ML::L::LINES - 1) / ML::L::LINES;
+    const unsigned grid = (unsigned)(wgs < device_cus() ? wgs : device_cus());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), ML::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, k, hk, R, chunks_per_grid, nchunks);
+    return check_launch("residual_both_rowpass");
+}
+
 int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
           double Lx, double rho, double nu, int precise, hipStream_t s, int seg_rows = 0, long seg_stride = 0) {
     if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
@@ -730,20 +996,21 @@ int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, 
     if (Lx == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: Lx, rho must be non-zero");
     const double ks = 2.0 * M_PI / Lx;
     SpecK k{ks / nx, ks / (rho * nx), nu * ks * ks / nx, 0.f};
+    const bool f64 = !spec_f32_mode(precise, nu, nx, Lx);
     if (seg_rows) {
         if (seg_rows < 4 || seg_rows > nx || (seg_rows & (seg_rows - 1)) || seg_stride < (long)seg_rows * ny)
             return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass_seg: seg_rows=%d must be a power of two in [4, nx=%d] and seg_stride=%ld >= seg_rows * ny", seg_rows, nx, seg_stride);
         SegK sg{__builtin_ctz((unsigned)seg_rows), seg_stride};
         return dispatch_n(nx, [&](auto n) {
             constexpr int N = decltype(n)::value;
-            return precise ? launch_xpass<N, double, true>(u, v, p, ru, rv, rd, batch, ny, k, s, sg)
-                           : launch_xpass<N, float, true>(u, v, p, ru, rv, rd, batch, ny, k, s, sg);
+            return f64 ? launch_xpass<N, double, true>(u, v, p, ru, rv, rd, batch, ny, k, s, sg)
+                       : launch_xpass<N, float, true>(u, v, p, ru, rv, rd, batch, ny, k, s, sg);
         });
     }
     return dispatch_n(nx, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        return precise ? launch_xpass<N, double>(u, v, p, ru, rv, rd, batch, ny, k, s)
-                       : launch_xpass<N, float>(u, v, p, ru, rv, rd, batch, ny, k, s);
+        return f64 ? launch_xpass<N, double>(u, v, p, ru, rv, rd, batch, ny, k, s)
+                   : launch_xpass<N, float>(u, v, p, ru, rv, rd, batch, ny, k, s);
     });
 }
 
@@ -755,10 +1022,11 @@ int ypass(const float* u, const float* v, const float* p, const float* up, const
     const double ks = 2.0 * M_PI / Ly;
     SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const long nrows = (long)batch * nx;
+    const bool f64 = !spec_f32_mode(precise, nu, ny, Ly);
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        return precise ? launch_ypass<N, double>(u, v, p, up, vp, ru, rv, rd, nrows, k, s)
-                       : launch_ypass<N, float>(u, v, p, up, vp, ru, rv, rd, nrows, k, s);
+        return f64 ? launch_ypass<N, double>(u, v, p, up, vp, ru, rv, rd, nrows, k, s)
+                   : launch_ypass<N, float>(u, v, p, up, vp, ru, rv, rd, nrows, k, s);
     });
 }
 
@@ -783,8 +1051,9 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
         const long nrows = (long)batch * nx;
-        return precise ? launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk)
-                       : launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk);
+        if (!spec_f32_mode(precise, nu, ny, Ly)) return launch_ypass<N, double, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk);
+        if constexpr (NNS_ROWMARCH) return launch_rowmarch<N>(u, v, p, up, vp, ru, rv, rd, fu, fv, fd, batch, nx, march_chunk_rows<N>(nrows, nx), k, fk, hk, s);
+        else return launch_ypass<N, float, true>(u, v, p, up, vp, ru, rv, rd, nrows, k, s, fu, fv, fd, nx, fk, hk);
     });
 }
 

@@ -15,6 +15,13 @@ KIND = {'dirichlet': 0, 'neumann': 1}
 SIDE = {'left': 0, 'right': 1, 'bottom': 2, 'top': 3}
 
 
+
+def _prec(precise):
+    """The C ABI's `precise` argument: 0 = all-float32 transforms (on differenced lines); 1 / True = the library picks -- all-float32 while
+    the viscous amplification nu pi N / (sqrt(3) L) <= 8, else float64 forward transforms; 2 = float64 forward transforms always."""
+    return 2 if (precise is not True and precise is not False and int(precise) >= 2) else int(bool(precise))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -271,7 +278,7 @@ def spec_residual(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, ou
         raise TypeError("spec_residual: float32 fields (the forward transforms run in float64 internally)")
     ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
     check(_lib.lib().nns_spec_residual_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
-                                           dt, Lx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_f32')
+                                           dt, Lx, Ly, rho, nu, _prec(precise), _stream()), 'nns_spec_residual_f32')
     return ru, rv, rd
 
 
@@ -287,7 +294,7 @@ def residual_both(u, v, p, u_prev, v_prev, dt, Lx, Ly, rho, nu, precise=True, ou
     so = out_spec if out_spec is not None else tuple(torch.empty_like(u) for _ in range(3))
     fn = _lib.lib().nns_residual_both_rowpass_f32 if rowpass_only else _lib.lib().nns_residual_both_f32
     check(fn(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny,
-             dt, Lx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_residual_both_f32')
+             dt, Lx, Ly, rho, nu, _prec(precise), _stream()), 'nns_residual_both_f32')
     return fo, so
 
 
@@ -297,7 +304,7 @@ def spec_residual_xpass(u, v, p, Lx, rho, nu, precise=True, out=None):
         raise TypeError("spec_residual_xpass: float32 fields")
     ru, rv, rd = out if out is not None else (torch.empty_like(u), torch.empty_like(u), torch.empty_like(u))
     check(_lib.lib().nns_spec_residual_xpass_f32(_p(u), _p(v), _p(p), _p(ru), _p(rv), _p(rd), B, nx, ny, Lx, rho, nu,
-                                                 int(bool(precise)), _stream()), 'nns_spec_residual_xpass_f32')
+                                                 _prec(precise), _stream()), 'nns_spec_residual_xpass_f32')
     return ru, rv, rd
 
 
@@ -312,7 +319,7 @@ def spec_residual_xpass_seg(recv, send, B, nx, nyl, seg_rows, Lx, rho, nu, preci
     e = recv.element_size()
     q = lambda t, f: t.data_ptr() + f * fs * e
     check(_lib.lib().nns_spec_residual_xpass_seg_f32(q(recv, 0), q(recv, 1), q(recv, 2), q(send, 0), q(send, 1), q(send, 2), B, nx, nyl,
-                                                     int(seg_rows), 3 * fs, Lx, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_xpass_seg_f32')
+                                                     int(seg_rows), 3 * fs, Lx, rho, nu, _prec(precise), _stream()), 'nns_spec_residual_xpass_seg_f32')
     return send
 
 
@@ -329,7 +336,7 @@ def residual_both_rowpass_halo(u, v, p, u_prev, v_prev, halo_top, halo_bot, sp_p
     so = sp_partials
     check(_lib.lib().nns_residual_both_rowpass_halo_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(halo_top), _p(halo_bot),
                                                         _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny,
-                                                        dt, dx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_residual_both_rowpass_halo_f32')
+                                                        dt, dx, Ly, rho, nu, _prec(precise), _stream()), 'nns_residual_both_rowpass_halo_f32')
     return fo, so
 
 
@@ -396,7 +403,7 @@ def spec_residual_ypass_(u, v, p, u_prev, v_prev, ru, rv, rd, dt, Ly, rho, nu, p
     if suf != '_f32':
         raise TypeError("spec_residual_ypass: float32 fields")
     check(_lib.lib().nns_spec_residual_ypass_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(ru), _p(rv), _p(rd), B, nx, ny,
-                                                 dt, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_ypass_f32')
+                                                 dt, Ly, rho, nu, _prec(precise), _stream()), 'nns_spec_residual_ypass_f32')
     return ru, rv, rd
 
 
@@ -636,7 +643,7 @@ def spec_derivs(f, Lx, Ly, want=('x', 'y', 'lap'), precise=True):
     B, nx, ny = _dims(f)
     out = {k: torch.empty_like(f) for k in want}
     ptr = lambda k: _p(out[k]) if k in out else None
-    check(_lib.lib().nns_spec_derivs_f32(_p(f), ptr('x'), ptr('y'), ptr('lap'), B, nx, ny, float(Lx), float(Ly), int(bool(precise)), _stream()),
+    check(_lib.lib().nns_spec_derivs_f32(_p(f), ptr('x'), ptr('y'), ptr('lap'), B, nx, ny, float(Lx), float(Ly), _prec(precise), _stream()),
           'nns_spec_derivs_f32')
     return out
 
@@ -651,7 +658,7 @@ def spec_residual_bwd(u, v, g_u, g_v, g_div, dt, Lx, Ly, rho, nu, precise=True, 
     gup, gvp = (torch.empty_like(u), torch.empty_like(u)) if want_prev else (None, None)
     check(_lib.lib().nns_spec_residual_bwd_f32(_p(u), _p(v), _p(g_u), _p(g_v), _p(g_div), _p(gu), _p(gv), _p(gp),
                                                _p(gup) if want_prev else None, _p(gvp) if want_prev else None,
-                                               B, nx, ny, dt, Lx, Ly, rho, nu, int(bool(precise)), _stream()), 'nns_spec_residual_bwd_f32')
+                                               B, nx, ny, dt, Lx, Ly, rho, nu, _prec(precise), _stream()), 'nns_spec_residual_bwd_f32')
     return gu, gv, gp, gup, gvp
 
 

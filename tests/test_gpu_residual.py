@@ -374,7 +374,7 @@ def test_fused_both_residuals(nx, ny, batch, gpu_device):
     d = [dev(a) for a in f]
     Lx, Ly = 2 * np.pi * nx / ny, 2 * np.pi
     fd_ref = ops.fd_residual(*d, DT, Lx / nx, Ly / ny, RHO, NU, 5)
-    for precise in (True, False):
+    for precise in (2, True, False):                                         # float64 forward transforms, the library's pick, all-float32
         sp_ref = ops.spec_residual(*d, DT, Lx, Ly, RHO, NU, precise)
         fo, so = ops.residual_both(*d, DT, Lx, Ly, RHO, NU, precise)
         for a, b in zip(so, sp_ref):
@@ -412,3 +412,85 @@ def test_column_pass_ragged_column_counts(nx, ny, gpu_device):
     ref = OP.spectral_xpart(*[a.astype(np.float64) for a in f], Lx, rho, nu)
     for g, r in zip(got, ref):
         assert g.shape == (3, nx, ny) and rel_l2(g.cpu().numpy(), r) <= TOL
+
+
+def _rough_fields(B, nx, ny, seed):
+    """Fields with energy at every wavenumber, generated on the device (batches too large to build on the host)."""
+    g = torch.Generator(device='cuda'); g.manual_seed(seed)
+    x = torch.arange(nx, device='cuda', dtype=torch.float32)[:, None] * (2 * np.pi / nx)
+    y = torch.arange(ny, device='cuda', dtype=torch.float32)[None, :] * (2 * np.pi / ny)
+    base = [torch.cos(x) * torch.sin(y), -torch.sin(x) * torch.cos(y), -0.25 * (torch.cos(2 * x) + torch.cos(2 * y))]
+    f = [(b[None] + 0.05 * torch.randn(B, nx, ny, device='cuda', generator=g)).contiguous() for b in base]
+    return f + [(f[0] * 0.999 + 0.001).contiguous(), (f[1] * 0.999 - 0.001).contiguous()]
+
+
+@pytest.mark.parametrize('B,nx,ny', [(40, 512, 1024), (64, 512, 512), (256, 256, 256), (1024, 128, 128), (4096, 64, 64)])
+def test_marching_row_pass_equals_separate_kernels(B, nx, ny, gpu_device):
+    """Batches large enough for the MARCHING fused row pass (spec_rowmarch_kernel: every line walks a chunk of consecutive rows, the
+    stencil's row above parked in LDS, the row below = the next row's prefetch; all-float32 mode), every row length: its spectral
+    outputs equal the separate column + row pass, its stencil outputs the standalone stencil kernel, grid b of the batch equals
+    the same grid evaluated in a small batch (one-row chunks) bit for bit, run-to-run bitwise; the oracle on one grid."""
+    from nns import ops
+    from oracle import periodic as OP
+    d = _rough_fields(B, nx, ny, seed=B + nx)
+    Lx, Ly = 2 * np.pi * nx / ny, 2 * np.pi
+    fo, so = ops.residual_both(*d, DT, Lx, Ly, RHO, NU, precise=False)
+    fo2, so2 = ops.residual_both(*d, DT, Lx, Ly, RHO, NU, precise=False)
+    sp = ops.spec_residual(*d, DT, Lx, Ly, RHO, NU, precise=False)
+    fd = ops.fd_residual(*d, DT, Lx / nx, Ly / ny, RHO, NU, 5)
+    small = [t[B - 2:].contiguous() for t in d]
+    fs, ss = ops.residual_both(*small, DT, Lx, Ly, RHO, NU, precise=False)                     # 2 grids: the same kernel with one-row chunks
+    for k in range(3):
+        assert torch.equal(fo[k], fo2[k]) and torch.equal(so[k], so2[k])
+        same_to_an_ulp(so[k], sp[k])
+        assert torch.equal(so[k][B - 2:], ss[k]) and torch.equal(fo[k][B - 2:], fs[k])       # chunk length does not change a bit
+        assert rel_l2(fo[k].cpu().numpy(), fd[k].cpu().numpy()) < 1e-6
+    f64 = [t[B - 1].cpu().numpy().astype(np.float64) for t in d]
+    ref_fd, ref_sp = OP.fd_residual(*f64, DT, Lx / nx, Ly / ny, RHO, NU, 5), OP.spectral_residual(*f64, DT, Lx, Ly, RHO, NU)
+    for k in range(3):
+        assert rel_l2(fo[k][B - 1].cpu().numpy(), ref_fd[k]) <= TOL and rel_l2(so[k][B - 1].cpu().numpy(), ref_sp[k]) <= TOL
+
+
+def test_marching_row_pass_on_a_row_slab(gpu_device):
+    """The marching row pass on a row slab (nx_local = 44 rows: chunks of 8 with a ragged last one; rows above / below the slab from the
+    halo messages) against the same rows of the full-grid evaluation."""
+    from nns import ops
+    B, nx, ny, nl, r0 = 400, 1024, 1024, 44, 100
+    d = _rough_fields(1, nx, ny, seed=3)
+    full_fd, full_sp = ops.residual_both(*d, DT, L, L, RHO, NU, precise=False)
+    part = ops.spec_residual_xpass(d[0], d[1], d[2], L, RHO, NU, precise=False)
+    loc = [t[:, r0:r0 + nl].expand(B, nl, ny).contiguous() for t in d]
+    pl = [t[:, r0:r0 + nl].expand(B, nl, ny).contiguous() for t in part]
+    top = torch.stack([t[:, r0 - 1].expand(B, ny) for t in d[:3]]).contiguous()
+    bot = torch.stack([t[:, r0 + nl].expand(B, ny) for t in d[:3]]).contiguous()
+    hf, hs = ops.residual_both_rowpass_halo(*loc, top, bot, pl, DT, L / nx, L, RHO, NU, precise=False)
+    for a, b in zip(hf, full_fd):
+        assert bool((a == a[0:1]).all())                                                       # every grid of the batch the same
+        assert rel_l2(a[B - 1].cpu().numpy(), b[0, r0:r0 + nl].cpu().numpy()) < 1e-6
+    for a, b in zip(hs, full_sp):
+        assert bool((a == a[0:1]).all())
+        same_to_an_ulp(a[B - 1], b[0, r0:r0 + nl])
+
+
+@pytest.mark.parametrize('n', [256, 1024])
+@pytest.mark.parametrize('nu', [2 * np.pi / 1000, 0.1, 1.0])
+def test_all_float32_mode_accuracy_and_the_precise_policy(n, nu, gpu_device):
+    """The all-float32 spectral mode (transforms of forward-differenced lines, bounded filters) against the float64 oracle on smooth and
+    on rough fields: within the 1e-5 bar at every viscosity.  precise=1 is the library's pick: bitwise the all-float32 result while
+    nu pi N / (sqrt(3) L) <= 8, bitwise the float64-forward result (precise=2) above."""
+    from nns import ops
+    from oracle import periodic as OP
+    rng = np.random.default_rng(n)
+    for rough in (False, True):
+        f = inputs(2, n)
+        if rough:
+            f = [a + (0.02 * rng.standard_normal(a.shape)).astype(np.float32) for a in f]
+        d = [dev(a) for a in f]
+        ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], DT, L, L, 1.3, nu)
+        r0, r1, r2 = (ops.spec_residual(*d, DT, L, L, 1.3, nu, precise=pr) for pr in (0, 1, 2))
+        for g, r in zip(r0, ref):
+            assert rel_l2(g.cpu().numpy(), r) <= TOL
+        for g, r in zip(r2, ref):
+            assert rel_l2(g.cpu().numpy(), r) <= 1e-6
+        pick = r0 if nu * np.pi * n / (np.sqrt(3) * L) <= 8 else r2
+        assert all(torch.equal(a, b) for a, b in zip(r1, pick))

@@ -10,9 +10,11 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(os.path.join(root, 'gpurun_out', 'pmc_%s_%s' % (c, tag), '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
-            s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass') if n in kn), None)          # spec_xpass also matches spec_xpass_split_kernel
+            s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass', 'spec_rowmarch') if n in kn), None)          # spec_xpass also matches spec_xpass_split_kernel
             if s == 'spec_ypass' and re.search(r'spec_ypass_kernel<[^>]*true>', kn):
                 s = 'both_rowpass'                              # spec_ypass_kernel<N, TF, FUSE_FD = true>
+            if s == 'spec_rowmarch':
+                s = 'both_rowpass'                              # the marching form of the fused row pass
             if s and r['Counter_Name'] == c:
                 acc[s].append(float(r['Counter_Value']))
     val[c] = {k: sum(v) / len(v) for k, v in acc.items()}

@@ -6,7 +6,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(f"{root}/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        short = next((n for n in ("fd_residual", "spec_xpass", "spec_ypass") if n in k), None)
+        short = next((n for n in ("fd_residual", "spec_xpass", "spec_ypass", "spec_rowmarch") if n in k), None)
         if not short: continue
         acc[short][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[short][r["Counter_Name"]] += 1
 for k in sorted(acc):
