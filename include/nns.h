@@ -247,17 +247,25 @@ int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, 
 /* Spectral back-end: d/dx <-> i kx, lap <-> -|k|^2 via LDS-resident 1-D FFTs (the operators are
  * separable, so no 2-D transform is materialised): pass 1 transforms columns (axis 0) and leaves
  * the x-part of the residual in r_u, r_v, r_div; pass 2 transforms rows (axis 1) and completes
- * them in place.  nx, ny powers of two in [64, 1024].  precise != 0: forward transforms and the
- * spectral multiply run in float64 (inverse in float32) -- needed for 1e-5 rel-L2 because forward
- * rounding noise is amplified by k; precise == 0: all-float32 (about 2e-4 rel-L2 at 1024). */
+ * them in place.  nx, ny powers of two in [64, 1024].
+ * `precise` (every nns_spec_residual_* / nns_residual_both_* entry point) selects the arithmetic of the forward transforms:
+ *   0  all-float32: the lines are forward-DIFFERENCED in physical space (exact in float32) and the spectral multiply becomes
+ *      a bounded filter, so the white rounding noise of a float32 transform is not amplified by k.  First derivatives come
+ *      out at float32 accuracy for any input; the viscous term keeps a relative amplification of rms nu pi N / (sqrt(3) L)
+ *      per axis (1.9 at 1024^2, nu = 2 pi / 1000: 1.1e-6 rel-L2 against the float64 oracle; <= 4e-6 measured for nu <= 1);
+ *   1  the library picks, per pass: all-float32 while that factor is <= 8, otherwise as 2;
+ *   2  forward transforms and spectral multiply in float64, inverse in float32 (2-4e-7 rel-L2), whatever the viscosity.
+ * (nns_spec_residual_bwd_f32 and nns_spec_derivs_f32: 0 = plain all-float32, non-zero = float64 forward.) */
 int nns_spec_residual_f32(const float* u, const float* v, const float* p, const float* u_prev,
                           const float* v_prev, float* r_u, float* r_v, float* r_div,
                           int batch, int nx, int ny, double dt, double Lx, double Ly,
                           double rho, double nu, int precise, void* stream);
 /* "Stencil + spectral residual on the same inputs" (the unit of BASELINE.json's metric) in two launches instead of three:
  * the spectral column pass, then ONE row pass that completes the spectral residual AND evaluates the FD 5-point residual
- * (the formula of nns_fd_residual_f32, float64 Laplacian): a row pass holds whole rows of u and v in registers, so the
- * stencil's j-1 / j+1 neighbours are lane rotates and rows i-1 / i+1 come from L2 -- the inputs cross HBM once less.
+ * (the formula of nns_fd_residual_f32; second differences as differences of exact float32 first differences): a row pass holds
+ * whole rows of u, v, p in registers, so the stencil's j-1 / j+1 neighbours are lane rotates.  Rows i-1 / i+1: in the all-float32
+ * mode every line of a workgroup marches down a chunk of consecutive rows (row above parked in LDS, row below = the next row's
+ * prefetch: no second read); in the float64-forward mode they are re-read from L2 / memory.
  * nx, ny powers of two in [64, 1024] as for nns_spec_residual_f32 (ny = 1024: one row per wave, whole-wave DPP rotates;
  * shorter rows share a wave and use ds_bpermute).  Results equal those of the two separate calls to rounding.
  * The six output fields must not overlap the inputs or each other (rows i-1 / i+1 of the inputs are read while other rows'

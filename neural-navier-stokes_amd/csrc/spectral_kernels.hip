@@ -402,6 +402,9 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
 // 8.5 + 8 KB per line), p in 16 registers.  The stencil phase then issues no global load at all; per chunk two extra rows are read
 // (2 / R of three streams).  Lines are independent, no workgroup barrier anywhere, as before.
 // ------------------------------------------------------------------------------------------
+#ifndef NNS_MARCH_NT_IN
+#define NNS_MARCH_NT_IN 1          // non-temporal hint on the row prefetch (each row is read once, bar the chunk edges): +0.5 % (same-box A/B)
+#endif
 template <int N>
 struct MarchLds {
     using L = SpecLds<N, float>;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_rowmarch_kernel(const float
             auto hook = [&](auto sc) {
                 if constexpr (decltype(sc)::value == 2 * FftPasses<N>::value - 1) {          // after the last forward pass: the row below
 #pragma unroll
-                    for (int m = 0; m < 16; ++m) { nu[m] = na[TPF * m]; nv[m] = nb[TPF * m]; np[m] = nc[TPF * m]; }
+                    for (int m = 0; m < 16; ++m) { nu[m] = ld_stream<NNS_MARCH_NT_IN>(na + TPF * m); nv[m] = ld_stream<NNS_MARCH_NT_IN>(nb + TPF * m); np[m] = ld_stream<NNS_MARCH_NT_IN>(nc + TPF * m); }
                 }
             };
             C2<float> a[16], b[16];

@@ -10,6 +10,10 @@ on batches of [B, nx, ny] float32 fields resident in HBM, with two derivative ba
 The reference has no such operator (motivation
 src/neural_spectral/derivations/derivation.tex:25-59); oracle/periodic.py defines it and the
 tests pin both back-ends to it (1e-5 rel-L2 in float32).  Axis 0 = x, axis 1 = y.
+
+``precise`` (spectral back-end; include/nns.h): False / 0 = all-float32 transforms of forward-differenced lines, True / 1 = the
+library picks that mode while its viscous amplification nu pi N / (sqrt(3) L) stays <= 8 and float64 forward transforms
+otherwise, 2 = float64 forward transforms always.
 """
 import math
 
