@@ -820,8 +820,14 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
             const long tn = t + gridDim.x;
             const bool has_next = tn < ntiles;
             if (NNS_SPLIT_EXP != 2) {
-            if (prev >= 0) store_tile(prev);                                    // under the transforms of tile t: tile t-1's partials out ...
-            if (has_next) load_tile(tn);                                        // ... and tile t+1's inputs in (same registers)
+#ifndef NNS_SPLIT_NOST
+#define NNS_SPLIT_NOST 0           // timing experiments (wrong results): no partial stores / no input loads after the first tile
+#endif
+#ifndef NNS_SPLIT_NOLD
+#define NNS_SPLIT_NOLD 0
+#endif
+            if (prev >= 0 && !NNS_SPLIT_NOST) store_tile(prev);                 // under the transforms of tile t: tile t-1's partials out ...
+            if (has_next && !NNS_SPLIT_NOLD) load_tile(tn);                     // ... and tile t+1's inputs in (same registers)
             }
             __syncthreads();                                                    // (1) the transform waves have written tile t's partials to the staging image
             // the exchange step: results out of the image, next inputs into it, slot for slot
