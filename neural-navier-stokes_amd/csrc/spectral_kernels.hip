@@ -40,32 +40,34 @@ __device__ __forceinline__ float wave_rol1(float x) {          // lane i <- lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
 }
 // left / right neighbour (column - 1 / + 1, periodic) of slot M of a row held as element tid + TPF m in slot m by the TPF lanes
-// of one line.  TPF = 64 (one row per wave): one whole-wave DPP rotate + a readlane of the adjacent slot for the end lane.
-// TPF < 64 (several rows per wave): two ds_bpermute per neighbour (own slot from lane - 1, adjacent slot from the line's
-// last lane for tid = 0).
+// of one line -- DPP only, no LDS crossbar for any row length: the in-line neighbour is a whole-wave rotate by one lane (the lane
+// it is wrong for -- the line's first / last -- takes the wrap value instead), the wrap value is the adjacent slot of the line's
+// other end: a readlane at TPF = 64 (one line per wave), one ds_bpermute at TPF = 32, a rotate within the 16-lane DPP row by TPF - 1 below
+// (TPF = 16, 8, 4 divide the row).  Round 2: the TPF < 64 forms used two ds_bpermute per neighbour (12 per point in the fused row pass).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_of(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 template <int M, int TPF>
 __device__ __forceinline__ float left_of(const float (&x)[16], int tid) {
-    if constexpr (TPF == 64) {
-        const float l = wave_ror1(x[M]);
-        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 15) & 15]), 63));
-        return tid == 0 ? w : l;
-    } else {
-        const int lane = threadIdx.x % kWave, first = lane - tid;                 // first lane of this line
-        const float l = __shfl(x[M], lane - 1), w = __shfl(x[(M + 15) & 15], first + TPF - 1);
-        return tid == 0 ? w : l;
-    }
+    const float l = wave_ror1(x[M]);
+    const float e = x[(M + 15) & 15];
+    float w;
+    if constexpr (TPF == 64) w = lane_of(e, 63);
+    else if constexpr (TPF == 32) w = __shfl(e, (int)((threadIdx.x % kWave) | 31));        // (two readlanes + a select measured slower than one ds_bpermute)
+    else w = dpp_mov<0x120 + (17 - TPF)>(e);                         // row_ror: lane i <- lane i - (17 - TPF) = i + TPF - 1 (mod 16)
+    return tid == 0 ? w : l;
 }
 template <int M, int TPF>
 __device__ __forceinline__ float right_of(const float (&x)[16], int tid) {
-    if constexpr (TPF == 64) {
-        const float r = wave_rol1(x[M]);
-        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[(M + 1) & 15]), 0));
-        return tid == 63 ? w : r;
-    } else {
-        const int lane = threadIdx.x % kWave, first = lane - tid;
-        const float r = __shfl(x[M], lane + 1), w = __shfl(x[(M + 1) & 15], first);
-        return tid == TPF - 1 ? w : r;
-    }
+    const float r = wave_rol1(x[M]);
+    const float e = x[(M + 1) & 15];
+    float w;
+    if constexpr (TPF == 64) w = lane_of(e, 0);
+    else if constexpr (TPF == 32) w = __shfl(e, (int)((threadIdx.x % kWave) & 32));
+    else w = dpp_mov<0x120 + (TPF - 1)>(e);                          // row_ror: lane i <- lane i - (TPF - 1) (mod 16)
+    return tid == TPF - 1 ? w : r;
 }
 
 
