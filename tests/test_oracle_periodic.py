@@ -106,3 +106,30 @@ def test_residual_vjp_is_the_adjoint_of_the_jacobian():
         grads = vjp(w[0], w[1], *g)
         rhs = sum(float((a * b).sum()) for a, b in zip(grads, d))
         assert abs(lhs - rhs) <= 1e-10 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+@pytest.mark.parametrize('n', [16, 64, 256])
+def test_forward_difference_filters_reproduce_the_spectral_derivatives(n):
+    """The identity behind the all-float32 device mode (csrc/spectral_kernels.hip, deriv_core DIFF32), in float64 where it is exact to
+    rounding: with D = FFT(d), d_j = f_{j+1} - f_j (periodic) and theta = 2 pi k / n,
+        i k FFT(f) = M1 D,     M1 = (k/2) (cot(theta/2) - i)          (0 at k = 0 and, for odd derivatives, at the Nyquist mode)
+        -k^2 FFT(f) = F2 D,    F2 = (k/2) (k + i k cot(theta/2))      (Nyquist mode kept: cot(pi/2) = 0)
+    so the x-derivative and second derivative of oracle/periodic.py's spectral_derivs come out of ONE transform of the differenced line."""
+    rng = np.random.default_rng(n)
+    L = 2.5
+    f = rng.standard_normal((3, n, n))
+    fx, _, _ = OP.spectral_derivs(f, L, L)
+    ks = 2 * np.pi / L
+    k = np.fft.fftfreq(n, 1.0 / n)                                     # integer wavenumbers
+    ko = k.copy(); ko[n // 2] = 0.0
+    ct = np.zeros(n)
+    nz = (k != 0) & (np.abs(k) != n // 2)
+    ct[nz] = np.abs(k[nz]) / np.tan(np.pi * np.abs(k[nz]) / n)        # the device's table: |k| cot(pi |k| / n), even in k
+    D = np.fft.fft(np.roll(f, -1, axis=1) - f, axis=1)
+    M1 = 0.5 * ks * (ct - 1j * ko)
+    F2 = 0.5 * ks * ks * (k * k + 1j * k * ct)
+    got_x = np.fft.ifft(D * M1[None, :, None], axis=1).real
+    got_xx = np.fft.ifft(D * F2[None, :, None], axis=1).real
+    want_xx = np.fft.ifft(np.fft.fft(f, axis=1) * (-(ks * k) ** 2)[None, :, None], axis=1).real
+    np.testing.assert_allclose(got_x, fx, atol=1e-10 * np.abs(fx).max())
+    np.testing.assert_allclose(got_xx, want_xx, atol=1e-10 * np.abs(want_xx).max())
