@@ -494,3 +494,21 @@ def test_all_float32_mode_accuracy_and_the_precise_policy(n, nu, gpu_device):
             assert rel_l2(g.cpu().numpy(), r) <= 1e-6
         pick = r0 if nu * np.pi * n / (np.sqrt(3) * L) <= 8 else r2
         assert all(torch.equal(a, b) for a, b in zip(r1, pick))
+
+
+@pytest.mark.parametrize('B', [3, 300, 1500])
+def test_marching_row_pass_chunk_lengths(B, gpu_device):
+    """The chunk length of the marching row pass follows the batch (64 x 256 grids: one-row chunks at B = 3, two rows at 300, eight at
+    1500): the same answers as the separate kernels at each, white-noise fields."""
+    from nns import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(B)
+    nx, ny = 64, 256
+    d = [torch.randn(B, nx, ny, device='cuda', generator=g) for _ in range(3)]
+    d += [d[0] * 0.999 + 0.001, d[1] * 0.999 - 0.001]
+    Lx, Ly = 2 * np.pi * nx / ny, 2 * np.pi
+    fo, so = ops.residual_both(*d, DT, Lx, Ly, 1.3, NU, precise=False)
+    sp = ops.spec_residual(*d, DT, Lx, Ly, 1.3, NU, precise=False)
+    fd = ops.fd_residual(*d, DT, Lx / nx, Ly / ny, 1.3, NU, 5)
+    for k in range(3):
+        same_to_an_ulp(so[k], sp[k])
+        assert rel_l2(fo[k].cpu().numpy(), fd[k].cpu().numpy()) < 1e-6
