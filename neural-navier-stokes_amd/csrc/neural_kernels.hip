@@ -825,6 +825,206 @@ __global__ __launch_bounds__(256) NNS_PK_ATTR void basis_loss_pk_kernel(const fl
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The one-sweep loss + gradient pass on the MATRIX cores (round 2).  The packed-FMA kernel above is bound by the vector rate
+// (3 K FMAs per element plus a cross-lane butterfly for the coefficient gradients: 2.9 ms for BASELINE config 5's 6.4 GB of
+// observations, 2.3 TB/s).  All three contractions are skinny GEMMs, and v_mfma_f32_16x16x4_f32 is an exact float32 FMA chain
+// at the packed-vector peak rate that leaves the vector pipe free:
+//     pred  [16 t  x 16 pix] = w  [16 t x KMAX]  f [KMAX x 16 pix]              KQ = KMAX / 4 MFMAs
+//     gbasis[KMAX  x 16 pix] += w^T[KMAX x 16 t] g [16 t x 16 pix]              4 MFMAs   (accumulated over all t in registers)
+//     gcoeff[16 t  x KMAX ]  += g [16 t x 16 pix] f^T[16 pix x KMAX]            4 MFMAs   (accumulated over the wave's pixel tiles)
+// A wave owns NPT = 4 pixel tiles (64 pixels) and walks the time rows in blocks of 16.  Layouts (lane l: lj = l % 16, lg = l / 16):
+// the prediction comes out as D[t = 4 lg + r][pix = lj]; the observations are loaded in exactly that layout (a tile is a STRIDED
+// pixel set, so that a lane's four tiles are one 16-byte access: four 256-byte row pieces per instruction), so g = pred - obs needs no shuffle, and register r of g IS the B operand of the gbasis product's
+// k-step r when the A operand is read from LDS as w[t = 4 lg + r][k = lj] (the contraction order over t is free).  Only the
+// coefficient gradient wants t on the lanes: g goes through a 16 x 17 LDS tile once per pixel tile (4 + 4 LDS instructions).
+// Every wave parks its gcoeff tile of a time block in LDS (plain stores, no barrier); at the end of a chunk of <= 176 rows the four
+// waves' tiles are summed and leave in one burst of global atomics (2.5 wave-instructions per 16 rows x 256 pixels).  Registers: ~100 (4 waves per SIMD), the observations of the next time block are in flight while
+// the current one is multiplied.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef NNS_MF_EXP
+#define NNS_MF_EXP 0               // timing experiments (wrong results): 1 no observation loads, 2 no coefficient-gradient part, 3 no LDS accumulation
+#endif
+constexpr int kMfNPT = 4;                                   // pixel tiles (of 16) per wave
+#ifndef NNS_MF_WAVES
+#define NNS_MF_WAVES 3             // waves per SIMD the register allocation is held to (0: the allocator decides -- 2 at K = 10, no spills)
+#endif
+#if NNS_MF_WAVES
+#define NNS_MF_ATTR __attribute__((amdgpu_waves_per_eu(NNS_MF_WAVES, NNS_MF_WAVES)))
+#else
+#define NNS_MF_ATTR
+#endif
+constexpr int kMfTCMax = 176;                               // time rows per chunk at most (11 blocks of 16)
+constexpr int kMfCwLd = 20;                                 // LDS row stride (floats) of the coefficient block and of the 16 x 16 tiles: with 20 both access
+                                                            // patterns of a tile -- [4 lg + r][lj] and [lj][4 s + lg] -- touch 64 distinct banks
+template <int KQ>
+__global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const float* __restrict__ coeff, const float* __restrict__ basis,
+                                                              const float* __restrict__ obs, double* __restrict__ sumsq,
+                                                              float* __restrict__ gcoeff, float* __restrict__ gbasis,
+                                                              int T, int K, int C, int P, int TC, int rows_per_split, int nsplit) {
+    constexpr int NPT = kMfNPT, LD = kMfCwLd;
+    static_assert(NPT == 4, "a lane's tiles are the four lanes of one 16-byte access");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* cw = reinterpret_cast<float*>(smem_raw);                               // [TC][LD]: w[t][k], zero for k >= K and padding rows
+    float* gtb = cw + (size_t)TC * LD;                                            // [4 waves][16][LD]: the transposing tile
+    float* gacc = gtb + 4 * 16 * LD;                                              // [TC / 16][4 waves][16][LD]: every wave's gcoeff tile of every time block of the chunk
+    const int c = blockIdx.y, tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave, lj = lane % 16, lg = lane / 16;
+    const int pix0 = (blockIdx.x * 4 + wave) * (NPT * 16);
+    const int t_lo = blockIdx.z * rows_per_split, t_hi = min(T, t_lo + rows_per_split);
+    float* gt = gtb + wave * 16 * LD;
+    // invariant operands: the basis functions of the wave's pixels in the two layouts the products need
+    // Pixel tile i of the wave is the STRIDED set {pix0 + 4 j + i, j = 0..15}: in the D layout (pix index j = lj) a lane's four tiles are
+    // then four consecutive pixels, and the observations of a time row, the basis values and the basis gradients move as 16-byte
+    // accesses (P is a multiple of 4 here: checked on the host) -- a wave instruction covers 4 rows x 256 contiguous bytes.
+    float Bf[NPT][KQ], fT[NPT][4];
+    const int pxl = pix0 + 4 * lj;                                                // this lane's first pixel (D layout)
+    const bool pok = pxl < P;                                                     // all four or none (P % 4 == 0)
+    const int pcl = pok ? pxl : P - 4;
+    const float pm = pok ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) {
+        const int k = 4 * s + lg;
+        const float4 v = (k < K && pok) ? *reinterpret_cast<const float4*>(&basis[((size_t)k * C + c) * P + pxl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        Bf[0][s] = v.x; Bf[1][s] = v.y; Bf[2][s] = v.z; Bf[3][s] = v.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pq = pix0 + 4 * (4 * s + lg);                                   // pixel index j = 4 s + lg of every tile
+        const float4 v = (lj < K && pq < P) ? *reinterpret_cast<const float4*>(&basis[((size_t)lj * C + c) * P + pq]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        fT[0][s] = v.x; fT[1][s] = v.y; fT[2][s] = v.z; fT[3][s] = v.w;
+    }
+    f32x4 gb[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) gb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double local = 0.0;
+    // The time rows [t_lo, t_hi) are walked in chunks of TC rows (the coefficient block and the gcoeff tiles of a chunk live in LDS);
+    // every pixel strip starts at its own chunk and wraps around, so that the bursts of gcoeff atomics at the chunk ends go to
+    // different rows.  The next chunk's coefficients are requested into registers when a chunk starts and written to LDS between
+    // the two barriers at its end; the observation prefetch runs across the chunk boundaries.
+    constexpr int LDG = KQ <= 3 ? 12 : LD;                                        // row stride of the parked gcoeff tiles (K <= 12: only 12 columns are kept)
+    constexpr int KM = 4 * KQ;                                                    // coefficient columns that can be non-zero
+    constexpr int CNR = (kMfTCMax * KM + 255) / 256;
+    const int nchunks = (t_hi - t_lo + TC - 1) / TC;
+    const int ci0 = (int)(((long)blockIdx.x * nchunks) / gridDim.x);
+    auto chunk_t0 = [&](int j) { int ci = ci0 + j; if (ci >= nchunks) ci -= nchunks; return t_lo + ci * TC; };
+    float cn[CNR];
+    auto load_coeffs = [&](int t0c) {
+        const int tnc = min(TC, t_hi - t0c);
+#pragma unroll
+        for (int q = 0; q < CNR; ++q) {
+            const int e = tid + 256 * q, tt = e / KM, k = e % KM;
+            cn[q] = (tt < tnc && k < K) ? coeff[((size_t)(t0c + tt) * K + k) * C + c] : 0.f;
+        }
+    };
+    auto store_coeffs = [&]() {
+#pragma unroll
+        for (int q = 0; q < CNR; ++q) {
+            const int e = tid + 256 * q, tt = e / KM, k = e % KM;
+            if (tt < TC) cw[tt * LD + k] = cn[q];
+        }
+    };
+    float4 on[4];                                                                 // row r of the NEXT block: this lane's four consecutive pixels = its four tiles
+    auto request = [&](int t0x, int b) {                                          // observations of time block b of the chunk at t0x, D layout
+        const int tnx = min(TC, t_hi - t0x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tt = 16 * b + 4 * lg + r;
+            const size_t row = ((size_t)(t0x + (tt < tnx ? tt : tnx - 1)) * C + c) * P;
+            on[r] = (NNS_MF_EXP == 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(&obs[row + pcl]);
+        }
+    };
+    for (int e = tid; e < TC * LD; e += 256) cw[e] = 0.f;                         // columns >= KM stay zero for the whole kernel
+    __syncthreads();
+    load_coeffs(chunk_t0(0));
+    request(chunk_t0(0), 0);
+    store_coeffs();
+    __syncthreads();
+    for (int j = 0; j < nchunks; ++j) {
+        const int t0 = chunk_t0(j);
+        const int tn = min(TC, t_hi - t0);
+        const int nb = (tn + 15) / 16;                                            // time blocks of this chunk
+        const bool more = j + 1 < nchunks;
+        const int t0n = more ? chunk_t0(j + 1) : t0;
+        if (more) load_coeffs(t0n);
+        for (int b = 0; b < nb; ++b) {
+            const int tb = 16 * b;
+            float o[NPT][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[0][r] = on[r].x; o[1][r] = on[r].y; o[2][r] = on[r].z; o[3][r] = on[r].w; }
+            if (b + 1 < nb) request(t0, b + 1); else request(t0n, more ? 0 : b);    // the next block is in flight while this one is multiplied
+            float Aw[KQ], AwT[4], rm[4];
+#pragma unroll
+            for (int s = 0; s < KQ; ++s) Aw[s] = cw[(tb + lj) * LD + 4 * s + lg];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { AwT[s] = cw[(tb + 4 * lg + s) * LD + lj]; rm[s] = tb + 4 * lg + s < tn ? 1.f : 0.f; }
+            f32x4 gc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KQ; ++s) acc = mfma4(Aw[s], Bf[i][s], acc);   // pred[t = 4 lg + r][pix = lj]
+                float g[4], rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    g[r] = acc[r] - o[i][r];
+                    const float mg = g[r] * (rm[r] * pm);
+                    rs = __builtin_fmaf(mg, mg, rs);
+                }
+                local += (double)rs;
+                // gbasis: padding rows have w = 0, out-of-range pixels are never stored -- no mask on g
+#pragma unroll
+                for (int s = 0; s < 4; ++s) gb[i] = mfma4(AwT[s], g[s], gb[i]);
+                if (NNS_MF_EXP == 2) continue;
+                // gcoeff: g with t on the lanes, through the transposing tile (rows = t, columns = pix)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gt[(4 * lg + r) * LD + lj] = g[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float gA[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) gA[s] = gt[lj * LD + 4 * s + lg];
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) gc = mfma4(gA[s], fT[i][s], gc);      // gcoeff[t = 4 lg + r][k = lj]
+            }
+            // this wave's tile of this time block is parked in LDS (plain stores, no barrier: the waves run free inside a chunk;
+            // ds_add_f32 into one shared tile measured 1.4 ms of the kernel's 3.0)
+            float* ga = gacc + (size_t)(b * 4 + wave) * 16 * LDG;
+            if (NNS_MF_EXP != 3 && lj < LDG)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ga[(4 * lg + r) * LDG + lj] = gc[r];
+        }
+        // the chunk's coefficient gradients: the four waves' tiles summed, one burst of global atomics; the next chunk's coefficients in
+        __syncthreads();
+        for (int e = tid; e < nb * 256; e += 256) {
+            const int tt = e / 16, k = e % 16, b = tt / 16, tr = tt % 16;
+            if (k < K && tt < tn) {
+                const float* ga = gacc + (size_t)(b * 4) * 16 * LDG + tr * LDG + k;
+                const float v = (ga[0] + ga[16 * LDG]) + (ga[2 * 16 * LDG] + ga[3 * 16 * LDG]);
+                atomicAdd(&gcoeff[((size_t)(t0 + tt) * K + k) * C + c], v);
+            }
+        }
+        if (more) store_coeffs();
+        __syncthreads();
+    }
+    for (int o2 = kWave / 2; o2 > 0; o2 >>= 1) local += __shfl_down(local, o2);
+    if (lane == 0) atomicAdd(sumsq, local);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = 4 * lg + r;
+        if (pok && k < K) {
+            float* dst = &gbasis[((size_t)k * C + c) * P + pxl];
+            if (nsplit > 1) {
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) atomicAdd(dst + i, gb[i][r]);
+            } else {
+                *reinterpret_cast<float4*>(dst) = make_float4(gb[0][r], gb[1][r], gb[2][r], gb[3][r]);
+            }
+        }
+    }
+}
+
 struct LossGeom { int TC, rows_per_split, nsplit, kmax; dim3 grid; size_t lds; };      // kmax = 0: the generic kernel
 inline LossGeom loss_geom(int T, int K, int C, int P) {
     LossGeom g;
@@ -1012,6 +1212,35 @@ NNS_API int nns_basis_loss_fused_f32(const float* coeff, const float* basis, con
     if (!coeff || !basis || !obs || !sumsq || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_fused: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: K=%d > %d", K, kMaxK);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: C must be <= 65535");
+#ifndef NNS_LOSS_MFMA
+#define NNS_LOSS_MFMA 1            // 1: basis_loss_mfma_kernel for K <= 16; 0: the packed-FMA kernel
+#endif
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (NNS_LOSS_MFMA && K <= 16 && P % 4 == 0 && al16(basis) && al16(obs) && al16(gbasis)) {
+        // pixel strips of 256 per workgroup; the time axis is split until ~8 workgroups per CU exist (4 run at once), whole 16-row blocks each
+        const int bx = (P + 255) / 256;
+        int ns = (2048 + bx * C - 1) / (bx * C);
+        const int max_ns = (T + 63) / 64;
+        if (ns > max_ns) ns = max_ns;
+        if (ns < 1) ns = 1;
+        if (ns > 65535) ns = 65535;
+        int rps = ((T + ns - 1) / ns + 15) / 16 * 16;
+        ns = (T + rps - 1) / rps;
+        // rows per chunk: coefficients (80 B per row) + the four waves' parked gradient tiles (192 B per row at K <= 12, 320 above) + the
+        // transposing tiles must leave room for 3 workgroups per CU (the register budget's occupancy)
+        const int tcmax = K <= 12 ? kMfTCMax : 112;
+        const int TC = rps < tcmax ? rps : tcmax;
+        const int ldg = K <= 12 ? 12 : kMfCwLd;
+        const size_t lds = ((size_t)TC * kMfCwLd + 4 * 16 * kMfCwLd + (size_t)(TC / 16) * 4 * 16 * ldg) * sizeof(float);
+        hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
+        if (e == hipSuccess && ns > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
+        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_fused: memset: %s", hipGetErrorString(e));
+        const dim3 grid(bx, C, ns);
+#define NNS_MF(KQ) hipLaunchKernelGGL((basis_loss_mfma_kernel<KQ>), grid, dim3(256), lds, S(stream), coeff, basis, obs, sumsq, gcoeff, gbasis, T, K, C, P, TC, rps, ns)
+        if (K <= 4) NNS_MF(1); else if (K <= 8) NNS_MF(2); else if (K <= 12) NNS_MF(3); else NNS_MF(4);
+#undef NNS_MF
+        return check_launch("basis_loss_fused");
+    }
     const LossGeom g = loss_geom(T, K, C, P);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
     if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
