@@ -857,10 +857,12 @@ constexpr int kMfNPT = 4;                                   // pixel tiles (of 1
 constexpr int kMfTCMax = 176;                               // time rows per chunk at most (11 blocks of 16)
 constexpr int kMfCwLd = 20;                                 // LDS row stride (floats) of the coefficient block and of the 16 x 16 tiles: with 20 both access
                                                             // patterns of a tile -- [4 lg + r][lj] and [lj][4 s + lg] -- touch 64 distinct banks
-template <int KQ>
+// MODE as in basis_loss_pk_kernel: 1 = gradients of scale * (pred - obs), 2 = gradients for the upstream gradient passed as `obs`
+// (no prediction), 3 = sum of squares AND the unscaled gradients.
+template <int KQ, int MODE>
 __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const float* __restrict__ coeff, const float* __restrict__ basis,
                                                               const float* __restrict__ obs, double* __restrict__ sumsq,
-                                                              float* __restrict__ gcoeff, float* __restrict__ gbasis,
+                                                              float* __restrict__ gcoeff, float* __restrict__ gbasis, float scale,
                                                               int T, int K, int C, int P, int TC, int rows_per_split, int nsplit) {
     constexpr int NPT = kMfNPT, LD = kMfCwLd;
     static_assert(NPT == 4, "a lane's tiles are the four lanes of one 16-byte access");
@@ -960,17 +962,28 @@ __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const 
             f32x4 gc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                float g[4];
+                if constexpr (MODE != 2) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < KQ; ++s) acc = mfma4(Aw[s], Bf[i][s], acc);   // pred[t = 4 lg + r][pix = lj]
-                float g[4], rs = 0.f;
+                    for (int s = 0; s < KQ; ++s) acc = mfma4(Aw[s], Bf[i][s], acc);   // pred[t = 4 lg + r][pix = lj]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    g[r] = acc[r] - o[i][r];
-                    const float mg = g[r] * (rm[r] * pm);
-                    rs = __builtin_fmaf(mg, mg, rs);
+                    for (int r = 0; r < 4; ++r) g[r] = acc[r] - o[i][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r] = o[i][r];
                 }
-                local += (double)rs;
+                if constexpr (MODE == 3) {
+                    float rs = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float mg = g[r] * (rm[r] * pm); rs = __builtin_fmaf(mg, mg, rs); }
+                    local += (double)rs;
+                }
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r] *= scale;
+                }
+                // (MODE 2: the clamped re-read of a padding row is harmless -- its w is 0 for gbasis and its gcoeff row is dropped at the flush)
                 // gbasis: padding rows have w = 0, out-of-range pixels are never stored -- no mask on g
 #pragma unroll
                 for (int s = 0; s < 4; ++s) gb[i] = mfma4(AwT[s], g[s], gb[i]);
@@ -1008,8 +1021,10 @@ __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const 
         if (more) store_coeffs();
         __syncthreads();
     }
-    for (int o2 = kWave / 2; o2 > 0; o2 >>= 1) local += __shfl_down(local, o2);
-    if (lane == 0) atomicAdd(sumsq, local);
+    if constexpr (MODE == 3) {
+        for (int o2 = kWave / 2; o2 > 0; o2 >>= 1) local += __shfl_down(local, o2);
+        if (lane == 0) atomicAdd(sumsq, local);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = 4 * lg + r;
@@ -1191,11 +1206,46 @@ NNS_API int nns_basis_loss_fwd_f32(const float* coeff, const float* basis, const
 }
 
 // g = scale * (pred - obs) (scale = upstream / loss).  gcoeff [T][K][C] is zeroed here and accumulated with atomics; gbasis is overwritten.
+#ifndef NNS_LOSS_MFMA
+#define NNS_LOSS_MFMA 1            // 1: basis_loss_mfma_kernel for K <= 16 (P a multiple of 4, 16-byte aligned fields); 0: the packed-FMA kernel
+#endif
+// Returns 1 when the shape is not the matrix-core kernel's (the caller falls back to the packed-FMA kernel), else the launch's status.
+template <int MODE>
+int launch_loss_mfma(const float* coeff, const float* basis, const float* obs, double* sumsq, float* gcoeff, float* gbasis, float scale,
+                     int T, int K, int C, int P, hipStream_t s, const char* what) {
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (!(NNS_LOSS_MFMA && K <= 16 && P % 4 == 0 && al16(basis) && al16(obs) && al16(gbasis))) return 1;
+    // pixel strips of 256 per workgroup; the time axis is split until ~8 workgroups per CU exist (3 run at once), whole 16-row blocks each
+    const int bx = (P + 255) / 256;
+    int ns = (2048 + bx * C - 1) / (bx * C);
+    const int max_ns = (T + 63) / 64;
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+    int rps = ((T + ns - 1) / ns + 15) / 16 * 16;
+    ns = (T + rps - 1) / rps;
+    // rows per chunk: coefficients (80 B per row) + the four waves' parked gradient tiles (192 B per row at K <= 12, 320 above) + the
+    // transposing tiles must leave room for 3 workgroups per CU (the register budget's occupancy)
+    const int tcmax = K <= 12 ? kMfTCMax : 112;
+    const int TC = rps < tcmax ? rps : tcmax;
+    const int ldg = K <= 12 ? 12 : kMfCwLd;
+    const size_t lds = ((size_t)TC * kMfCwLd + 4 * 16 * kMfCwLd + (size_t)(TC / 16) * 4 * 16 * ldg) * sizeof(float);
+    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), s);
+    if (e == hipSuccess && ns > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), s);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
+    const dim3 grid(bx, C, ns);
+#define NNS_MF(KQ) hipLaunchKernelGGL((basis_loss_mfma_kernel<KQ, MODE>), grid, dim3(256), lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, TC, rps, ns)
+    if (K <= 4) NNS_MF(1); else if (K <= 8) NNS_MF(2); else if (K <= 12) NNS_MF(3); else NNS_MF(4);
+#undef NNS_MF
+    return check_launch(what);
+}
+
 NNS_API int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const float* obs, float scale, float* gcoeff, float* gbasis,
                                    int T, int K, int C, int P, void* stream) {
     if (!coeff || !basis || !obs || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_bwd: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: K=%d > %d", K, kMaxK);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: C must be <= 65535");
+    if (int rc = launch_loss_mfma<1>(coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P, S(stream), "basis_loss_bwd"); rc != 1) return rc;
     const LossGeom g = loss_geom(T, K, C, P);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
     if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
@@ -1212,35 +1262,7 @@ NNS_API int nns_basis_loss_fused_f32(const float* coeff, const float* basis, con
     if (!coeff || !basis || !obs || !sumsq || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_loss_fused: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: K=%d > %d", K, kMaxK);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: C must be <= 65535");
-#ifndef NNS_LOSS_MFMA
-#define NNS_LOSS_MFMA 1            // 1: basis_loss_mfma_kernel for K <= 16; 0: the packed-FMA kernel
-#endif
-    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (NNS_LOSS_MFMA && K <= 16 && P % 4 == 0 && al16(basis) && al16(obs) && al16(gbasis)) {
-        // pixel strips of 256 per workgroup; the time axis is split until ~8 workgroups per CU exist (4 run at once), whole 16-row blocks each
-        const int bx = (P + 255) / 256;
-        int ns = (2048 + bx * C - 1) / (bx * C);
-        const int max_ns = (T + 63) / 64;
-        if (ns > max_ns) ns = max_ns;
-        if (ns < 1) ns = 1;
-        if (ns > 65535) ns = 65535;
-        int rps = ((T + ns - 1) / ns + 15) / 16 * 16;
-        ns = (T + rps - 1) / rps;
-        // rows per chunk: coefficients (80 B per row) + the four waves' parked gradient tiles (192 B per row at K <= 12, 320 above) + the
-        // transposing tiles must leave room for 3 workgroups per CU (the register budget's occupancy)
-        const int tcmax = K <= 12 ? kMfTCMax : 112;
-        const int TC = rps < tcmax ? rps : tcmax;
-        const int ldg = K <= 12 ? 12 : kMfCwLd;
-        const size_t lds = ((size_t)TC * kMfCwLd + 4 * 16 * kMfCwLd + (size_t)(TC / 16) * 4 * 16 * ldg) * sizeof(float);
-        hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
-        if (e == hipSuccess && ns > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
-        if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_fused: memset: %s", hipGetErrorString(e));
-        const dim3 grid(bx, C, ns);
-#define NNS_MF(KQ) hipLaunchKernelGGL((basis_loss_mfma_kernel<KQ>), grid, dim3(256), lds, S(stream), coeff, basis, obs, sumsq, gcoeff, gbasis, T, K, C, P, TC, rps, ns)
-        if (K <= 4) NNS_MF(1); else if (K <= 8) NNS_MF(2); else if (K <= 12) NNS_MF(3); else NNS_MF(4);
-#undef NNS_MF
-        return check_launch("basis_loss_fused");
-    }
+    if (int rc = launch_loss_mfma<3>(coeff, basis, obs, sumsq, gcoeff, gbasis, 1.f, T, K, C, P, S(stream), "basis_loss_fused"); rc != 1) return rc;
     const LossGeom g = loss_geom(T, K, C, P);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
     if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
@@ -1255,6 +1277,7 @@ NNS_API int nns_basis_expand_bwd_f32(const float* coeff, const float* basis, con
     if (!coeff || !basis || !grad_pred || !gcoeff || !gbasis || T < 1 || K < 1 || C < 1 || P < 1) return fail(NNS_ERR_INVALID_ARG, "basis_expand_bwd: bad args");
     if (K > kMaxK) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: K=%d > %d", K, kMaxK);
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: C must be <= 65535");
+    if (int rc = launch_loss_mfma<2>(coeff, basis, grad_pred, nullptr, gcoeff, gbasis, 1.f, T, K, C, P, S(stream), "basis_expand_bwd"); rc != 1) return rc;
     const LossGeom g = loss_geom(T, K, C, P);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
     if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
