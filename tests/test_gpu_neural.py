@@ -313,9 +313,12 @@ def test_gru_baselines_vs_golden(gpu_device):
 
 @pytest.mark.parametrize('shape', [
     # (T, K, C, P): every coefficient padding of the packed kernel (KMAX 4, 8, 10, 12, 16), ragged pixel tails, time
-    # rows that do not fill a butterfly group, one and several time splits; and the generic kernel (K > 16, small P)
+    # rows that do not fill a butterfly group, one and several time splits; and the generic kernel (K > 16, small P).
+    # P % 4 == 0 and K <= 16 take the matrix-core gradient kernels, the others the packed-FMA ones (both stay covered)
     (37, 3, 3, 4096), (50, 7, 2, 5000), (64, 10, 3, 16384), (19, 10, 1, 4100), (41, 12, 3, 4096 + 1024 + 7),
-    (33, 16, 2, 8192), (700, 10, 3, 4096), (2, 9, 3, 65536), (23, 20, 3, 4096), (29, 10, 3, 300)])
+    (33, 16, 2, 8192), (700, 10, 3, 4096), (2, 9, 3, 65536), (23, 20, 3, 4096), (29, 10, 3, 300),
+    # the matrix-core gradient kernel (K <= 16, P % 4 == 0): smallest shapes, every K quad, a chunk boundary (T > 176) with a ragged tail
+    (1, 1, 1, 4), (5, 2, 1, 8), (17, 16, 1, 64), (300, 13, 2, 260), (400, 5, 1, 1028)])
 def test_basis_loss_kernels_direct(shape, gpu_device):
     """nns_basis_loss_fwd / _bwd / nns_basis_expand_bwd against float64 tensor contractions (rel-L2 2e-6: float32
     accumulation over up to 65536 pixels / 700 rows)."""
