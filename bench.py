@@ -132,8 +132,8 @@ def cpu_baseline_all_cores(n, budget_s=8.0, max_procs=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=30)       # the first ~25 steps after start-up run 3 % slower (tools/ramp_check.py)
     ap.add_argument('--n', type=int, default=1024)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--distinct', type=int, default=8, help='distinct synthetic grids generated on the host (tiled to --batch)')
