@@ -39,7 +39,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # algorithmic (compulsory) HBM bytes per grid point, float32 fields -- derivation in DESIGN.md
-BYTES_PER_PT = {'fd_residual': 32.0, 'spec_xpass': 24.0, 'spec_ypass': 44.0,
+BYTES_PER_PT = {'fd_residual': 32.0, 'spec_xpass': 24.0, 'spec_ypass': 44.0, 'both_rowpass_back_to_back': 56.0,
                 # fused row pass (nns_residual_both_f32): u, v, p, u_prev, v_prev + 3 column-pass partials in, 3 + 3 residuals out
                 'both_rowpass': 56.0}
 STEP_BYTES_TWO_PASS = 80.0     # column pass (3 in + 3 partials out) + fused row pass (5 in + 3 partials in + 6 out)
@@ -257,11 +257,25 @@ def main():
             'spec_xpass': time_kernel(lambda: ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, prec, out=out_sp), iters),
             'spec_ypass': time_kernel(lambda: ops.spec_residual_ypass_(*f, *out_sp, dt, L, rho, nu, prec), iters),
         }
-        if fused:                              # the launches the timed step is made of
-            ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, prec, out=out_sp)
-            kt = {'spec_xpass': standalone['spec_xpass'],
-                  'both_rowpass': time_kernel(lambda: ops.residual_both(*f, dt, L, L, rho, nu, prec, out_fd=out_fd, out_spec=out_sp,
-                                                                         rowpass_only=True), iters)}
+        if fused:
+            # the launches the timed step is made of, timed IN the step's own sequence (column pass, row pass, column pass, ...): HIP events
+            # on the launch stream between the two launches of every step -- a row pass that follows the column pass finds part of the
+            # partials in the Infinity Cache, one that follows another row pass (a back-to-back loop of the same launch) does not
+            def rowpass():
+                ops.residual_both(*f, dt, L, L, rho, nu, prec, out_fd=out_fd, out_spec=out_sp, rowpass_only=True)
+
+            def xpass():
+                ops.spec_residual_xpass(f[0], f[1], f[2], L, rho, nu, prec, out=out_sp)
+            for _ in range(5):
+                xpass(); rowpass()
+            torch.cuda.synchronize()
+            evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(iters)]
+            for e0, e1, e2 in evs:
+                e0.record(); xpass(); e1.record(); rowpass(); e2.record()
+            torch.cuda.synchronize()
+            kt = {'spec_xpass': sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / iters,
+                  'both_rowpass': sum(e1.elapsed_time(e2) for _, e1, e2 in evs) / iters}
+            standalone['both_rowpass_back_to_back'] = time_kernel(rowpass, iters)
         else:
             kt = dict(standalone)
         dom = max(kt, key=kt.get)
