@@ -237,8 +237,8 @@ int nns_fd_residual_bwd_f64(const double* u, const double* v, const double* g_u,
                             int batch, int nx, int ny, double dt, double dx, double dy,
                             double rho, double nu, int stencil, void* stream);
 /* Vector-Jacobian product of the spectral residual (oracle/periodic.py: spectral_residual_vjp): two fused passes like
- * the forward (columns, then rows), three packed forward (float64 when precise) and three inverse (float32) LDS-resident
- * transforms per line -- the conjugate spectral multiplies.  grad_u_prev / grad_v_prev may be null.  nx, ny powers of
+ * the forward (columns, then rows), three packed forward (`precise` as for nns_spec_residual_f32) and three inverse (float32)
+ * LDS-resident transforms per line -- the conjugate spectral multiplies.  grad_u_prev / grad_v_prev may be null.  nx, ny powers of
  * two in [64, 1024]. */
 int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,
                               float* grad_u, float* grad_v, float* grad_p, float* grad_u_prev, float* grad_v_prev,
@@ -255,7 +255,8 @@ int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, 
  *      per axis (1.9 at 1024^2, nu = 2 pi / 1000: 1.1e-6 rel-L2 against the float64 oracle; <= 4e-6 measured for nu <= 1);
  *   1  the library picks, per pass: all-float32 while that factor is <= 8, otherwise as 2;
  *   2  forward transforms and spectral multiply in float64, inverse in float32 (2-4e-7 rel-L2), whatever the viscosity.
- * (nns_spec_residual_bwd_f32 and nns_spec_derivs_f32: 0 = plain all-float32, non-zero = float64 forward.) */
+ * nns_spec_residual_bwd_f32 follows the same rule (its three packed pairs per line are differenced the same way);
+ * nns_spec_derivs_f32: 0 = plain all-float32, non-zero = float64 forward. */
 int nns_spec_residual_f32(const float* u, const float* v, const float* p, const float* u_prev,
                           const float* v_prev, float* r_u, float* r_v, float* r_div,
                           int batch, int nx, int ny, double dt, double Lx, double Ly,

@@ -7,7 +7,8 @@
 //   y-pass (rows):     grad_u = GU + a/dt           - [D_y(a v)     + nu L_y a]
 //                      grad_v = GV + b/dt + a u_y + b v_y - [D_y(b v + d) + nu L_y b]
 //                      grad_p = GP - (D_y b)/rho,   grad_u_prev = -a/dt,  grad_v_prev = -b/dt (optional)
-// Per line three packed forward transforms (float64) and three inverse ones (float32), on the forward's FFT engine:
+// Per line three packed forward transforms (float64, or float32 on forward-differenced lines: the forward's `precise` policy) and three
+// inverse ones (float32), on the forward's FFT engine:
 //   Z3 = FFT(f + i g)   ->  ifft(i k Z3)            = (f', g')            (f, g) = (u, v)
 //   Z2 = FFT(a + i b)   ->  ifft(i k Z2)            = (a', b')            one component is used per pass
 //   Z1 = FFT(s1 + i s2) ->  ifft(i k Z1 - nu k^2 Z2) = (D s1 + nu L a, D s2 + nu L b)
@@ -36,8 +37,78 @@ __device__ __forceinline__ void adj_core(const float (&ff)[16], const float (&gf
     const C2<float>* tabI2 = tabI + N / 2;
     C2<TF>* xbF = reinterpret_cast<C2<TF>*>(xb_raw);
     C2<float>* xbI = reinterpret_cast<C2<float>*>(xb_raw);
-    C2<TF> z[16];
     C2<float> e[16];
+#ifndef NNS_F32_DIFF
+#define NNS_F32_DIFF 1
+#endif
+    if constexpr (sizeof(TF) == 4 && NNS_F32_DIFF) {
+        // all-float32 mode, as the forward's (spectral_kernels.hip, deriv_core): every packed pair is forward-DIFFERENCED in physical space,
+        // FFT(d) = (e^{i theta} - 1) FFT(f), and the spectral multiplies become the bounded filters
+        //     i k   FFT(f) = M1 D,  M1 = (k / 2)(cot(theta / 2) - i);      -nu k^2 FFT(f) = (nu k / 2)(k + i k cot(theta / 2)) D
+        const float* ctab = reinterpret_cast<const float*>(tabI + N / 2 + Pass2<N>::ENTRIES);
+        const float c1h = (float)(0.5 * k.c1), c2h = (float)(0.5 * k.c2);
+        auto diff_fft = [&](const float (&p)[16], const float (&q)[16], C2<float> (&zv)[16]) {
+            static_for<0, 16>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                zv[m].x = right_of<m, N / 16>(p, tid) - p[m];
+                zv[m].y = right_of<m, N / 16>(q, tid) - q[m];
+            });
+            fft_line<float, N, false>(zv, tabI, tabI2, xbI, tid);
+        };
+        C2<float> zv[16];
+        // ---- (f', g')
+        diff_fft(ff, gf, zv);
+        int te = tid;
+        asm volatile("" : "+v"(te), "+v"(zv[0].x));
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            int ko, ke;
+            wavenumber<N, m>(te, ko, ke);
+            const float ar = ctab[ke < 0 ? -ke : ke] * c1h, ai = (float)ko * c1h;
+            e[m].x = ar * zv[m].x + ai * zv[m].y; e[m].y = ar * zv[m].y - ai * zv[m].x;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        fft_line<float, N, true>(e, tabI, tabI2, xbI, tid);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) w[m] = af[m] * e[m].x + bf[m] * e[m].y;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- a', b' and the viscous term  -nu k^2 Z2  (kept in c)
+        diff_fft(af, bf, zv);
+        te = tid;
+        asm volatile("" : "+v"(te), "+v"(zv[0].x));
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            int ko, ke;
+            wavenumber<N, m>(te, ko, ke);
+            const float ct = ctab[ke < 0 ? -ke : ke];
+            const float ar = ct * c1h, ai = (float)ko * c1h;
+            e[m].x = ar * zv[m].x + ai * zv[m].y; e[m].y = ar * zv[m].y - ai * zv[m].x;
+            const float kf = (float)ke * c2h;
+            const float br = kf * (float)ke, bi = kf * ct;                   // -nu k^2 Z2 = (br + i bi) D
+            c[m].x = br * zv[m].x - bi * zv[m].y; c[m].y = br * zv[m].y + bi * zv[m].x;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        fft_line<float, N, true>(e, tabI, tabI2, xbI, tid);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) da[m] = USE_A ? e[m].x : e[m].y;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- D s1 + nu L a,  D s2 + nu L b
+        diff_fft(s1, s2, zv);
+        te = tid;
+        asm volatile("" : "+v"(te), "+v"(zv[0].x));
+        static_for<0, 16>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            int ko, ke;
+            wavenumber<N, m>(te, ko, ke);
+            const float ar = ctab[ke < 0 ? -ke : ke] * c1h, ai = (float)ko * c1h;
+            c[m].x += ar * zv[m].x + ai * zv[m].y; c[m].y += ar * zv[m].y - ai * zv[m].x;
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        fft_line<float, N, true>(c, tabI, tabI2, xbI, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
+    C2<TF> z[16];
     // ---- (f', g')
 #pragma unroll
     for (int m = 0; m < 16; ++m) { z[m].x = (TF)ff[m]; z[m].y = (TF)gf[m]; }
@@ -289,13 +360,13 @@ NNS_API int nns_spec_residual_bwd_f32(const float* u, const float* v, const floa
     const AdjK kyp{ky / ny, nu * ky * ky / ny, (float)(1.0 / rho), (float)(1.0 / dt)};
     int rc = dispatch_n(nx, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        return precise ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s)
-                       : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s);
+        return !spec_f32_mode(precise, nu, nx, Lx) ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s)
+                                                  : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s);
     });
     if (rc) return rc;
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
-        return precise ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s)
-                       : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s);
+        return !spec_f32_mode(precise, nu, ny, Ly) ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s)
+                                                  : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s);
     });
 }

@@ -33,44 +33,6 @@ using namespace nns::spec;
 
 namespace {
 
-__device__ __forceinline__ float wave_ror1(float x) {          // lane i <- lane i-1, lane 0 <- lane 63
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float wave_rol1(float x) {          // lane i <- lane i+1, lane 63 <- lane 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
-}
-// left / right neighbour (column - 1 / + 1, periodic) of slot M of a row held as element tid + TPF m in slot m by the TPF lanes
-// of one line -- DPP only, no LDS crossbar for any row length: the in-line neighbour is a whole-wave rotate by one lane (the lane
-// it is wrong for -- the line's first / last -- takes the wrap value instead), the wrap value is the adjacent slot of the line's
-// other end: a readlane at TPF = 64 (one line per wave), one ds_bpermute at TPF = 32, a rotate within the 16-lane DPP row by TPF - 1 below
-// (TPF = 16, 8, 4 divide the row).  Round 2: the TPF < 64 forms used two ds_bpermute per neighbour (12 per point in the fused row pass).
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float lane_of(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
-template <int M, int TPF>
-__device__ __forceinline__ float left_of(const float (&x)[16], int tid) {
-    const float l = wave_ror1(x[M]);
-    const float e = x[(M + 15) & 15];
-    float w;
-    if constexpr (TPF == 64) w = lane_of(e, 63);
-    else if constexpr (TPF == 32) w = __shfl(e, (int)((threadIdx.x % kWave) | 31));        // (two readlanes + a select measured slower than one ds_bpermute)
-    else w = dpp_mov<0x120 + (17 - TPF)>(e);                         // row_ror: lane i <- lane i - (17 - TPF) = i + TPF - 1 (mod 16)
-    return tid == 0 ? w : l;
-}
-template <int M, int TPF>
-__device__ __forceinline__ float right_of(const float (&x)[16], int tid) {
-    const float r = wave_rol1(x[M]);
-    const float e = x[(M + 1) & 15];
-    float w;
-    if constexpr (TPF == 64) w = lane_of(e, 0);
-    else if constexpr (TPF == 32) w = __shfl(e, (int)((threadIdx.x % kWave) & 32));
-    else w = dpp_mov<0x120 + (TPF - 1)>(e);                          // row_ror: lane i <- lane i - (TPF - 1) (mod 16)
-    return tid == TPF - 1 ? w : r;
-}
-
-
 // The shared core: from the line's u, v, p (element tid + TPF*m in slot m) produce
 //   a = (f_u', f_v')  and  b = (L_u, L_v)  with the pressure-gradient term added to the real part
 //   (P_IN_REAL, x-pass) or the imaginary part (y-pass) of b.
@@ -947,19 +909,6 @@ int launch_ypass(const float* u, const float* v, const float* p, const float* up
     const unsigned grid = (unsigned)(niter < gmax ? niter : gmax);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kSpecThreads), L::TOTAL, s, u, v, p, up, vp, ru, rv, rd, fu, fv, fd, nx, fk, nrows, k, hk);
     return check_launch("spec_residual_ypass");
-}
-
-// Which arithmetic a `precise` request gets.  The all-float32 mode (deriv_core, DIFF32) computes first derivatives at float32 accuracy
-// for any input; its viscous term carries an amplification of nu |k| relative to them, rms nu pi N / (sqrt(3) L) over the spectrum
-// (1.9 at the headline configuration: 1.1e-6 rel-L2 against the float64 oracle, 4e-6 worst case over nu <= 1 on resolved fields;
-// tools/spec_accuracy_f32.py, profiles/r02_accuracy_f32diff.json).  precise = 1 takes it while that factor is <= 8 and the float64
-// forward transform otherwise; precise = 0 always, precise >= 2 never (NNS_SPEC_F64=1 in the environment: as precise = 2).
-constexpr double kF32AmpMax = 8.0;
-inline bool spec_f32_mode(int precise, double nu, int n, double len) {
-    if (!precise) return true;
-    static const bool force64 = [] { const char* e = getenv("NNS_SPEC_F64"); return e && atoi(e) != 0; }();
-    if (precise >= 2 || force64) return false;
-    return std::fabs(nu) * M_PI * n / (1.7320508075688772 * std::fabs(len)) <= kF32AmpMax;
 }
 
 inline int device_cus() {
