@@ -11,10 +11,18 @@ passes, csrc/spectral_kernels.hip).  One residual update = one grid point throug
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: the batch axis is the unit that shards (independent grids): every rank owns its own 64
-grids, no data-path collective, "scaling": "weak"; timing = barrier + synchronize on both sides,
-max over ranks.  (The slab-decomposed single-grid mode with RCCL halo / all-to-all is exercised
-by `--mode slab`, see nns/slab.py.)
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: N fresh child
+processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU) before anything in this process has touched the
+GPU, relays rank 0's JSON line and exits with the children's status.  Under `torch.distributed.run` (WORLD_SIZE set) it
+is one of the ranks.
+
+N > 1, default `--mode slab` (BASELINE.json's north star, config 4): the SAME 64 grids are slab-decomposed by rows over
+the ranks -- nearest-neighbour halo send/recv for the stencil, two all-to-all transposes per spectral evaluation, batch
+chunks pipelined so the collectives overlap the kernels (nns/slab.py) -- "scaling": "strong", `value` = 64 x 1024^2
+points / step time (max over ranks).  The same run also reports, as `batch_sharded`, the embarrassingly parallel
+alternative (every rank its own 64 grids, no data-path collective, weak scaling), `transport` (the backend really used),
+`rccl_ranks` (a device all-reduce of ones) and `phases` (per-phase times of one un-pipelined evaluation).  If the slab
+run fails or hangs, the self-launcher re-runs the ranks with `--mode batch` and says so in `launcher`.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- for the dominant kernel: algorithmic bytes per launch / its average launch time,
@@ -129,6 +137,115 @@ def cpu_baseline_all_cores(n, budget_s=8.0, max_procs=16):
                 sample='%d processes x (FD 5-point + rfft2 spectral residual) of one %dx%d float64 grid each, %.0f s' % (procs, n, n, budget_s))
 
 
+def slab_phases(sl, f, iters):
+    """One un-pipelined SlabResidual.both evaluation, phase by phase (ms, mean over `iters`): HIP events on the launch stream around
+    every phase, the collectives waited on that stream, a device synchronisation between phases.  Same kernels and messages as
+    the timed step, without the overlap."""
+    u, v, p, up, vp = f
+    B, nloc, ny = u.shape
+    P, nyl, c = sl.P, sl.nyloc, sl.compute
+    shape = (P, 3, B, nloc, nyl)
+    send, recv, back, got = (sl._buf(('ph', i), shape, u) for i in range(4))
+    parts = [torch.empty_like(u) for _ in range(3)]
+    out_fd = tuple(torch.empty_like(u) for _ in range(3))
+    acc = {}
+
+    def timed(name, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(); e1.record()
+        torch.cuda.synchronize()
+        acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+        return r
+    for it in range(iters + 1):
+        if it == 1:
+            acc.clear()                                        # first round = warm-up
+        h, top, bot = timed('halo_pack_and_post', lambda: sl.start_halo([u, v, p], tag='ph'))
+        timed('transpose_pack', lambda: c.transpose_pack([u, v, p], send, P))
+        timed('all_to_all_1', lambda: sl.tr.all_to_all(recv, send).wait())
+        timed('column_pass', lambda: c.spec_xpass_seg(recv, back, B, sl.nx, nyl, nloc, sl.Lx, sl.rho, sl.nu, sl.precise))
+        timed('all_to_all_2', lambda: sl.tr.all_to_all(got, back).wait())
+        timed('transpose_unpack', lambda: c.transpose_unpack(got, parts, P))
+        timed('halo_wait', lambda: h.wait())
+        timed('row_pass', lambda: c.both_rowpass_halo(u, v, p, up, vp, top, bot, parts, sl.dt, sl.dx, sl.Ly, sl.rho, sl.nu, sl.precise, out_fd=out_fd))
+    return {k: v / iters for k, v in acc.items()}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(n, argv, timeout_s, script=None):
+    """Start n fresh child ranks of this script (one per GPU), wait for them (bounded), return (rc, rank 0's stdout lines, note).
+    Children are ended by their exact PIDs when one fails or the time is up."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=(r == 0)))
+    import threading
+    lines = []
+    rd = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().splitlines()), daemon=True)
+    rd.start()
+    t_end = time.monotonic() + timeout_s
+    note, rc = None, 0
+    while True:
+        codes = [q.poll() for q in procs]
+        if all(c is not None for c in codes):
+            rc = next((c for c in codes if c != 0), 0)
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.monotonic() > t_end:
+            note = ('rank %d exited with status %d' % bad[0]) if bad else ('no result after %.0f s' % timeout_s)
+            time.sleep(2.0 if bad else 0.0)                           # let the other ranks notice and report
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+            t_kill = time.monotonic() + 10
+            while any(q.poll() is None for q in procs) and time.monotonic() < t_kill:
+                time.sleep(0.2)
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            rc = bad[0][1] if bad else 124
+            break
+        time.sleep(0.2)
+    rd.join(timeout=5)
+    return rc, lines, note
+
+
+def self_launch(args, argv=None, script=None):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: run the N ranks as child processes and relay rank 0's JSON line.
+    The default mode is slab; if that attempt fails or hangs the ranks are started again in batch mode (fresh processes) and the
+    line says so -- a measured weak-scaling number with the slab failure on record instead of no line at all."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    modes = [args.mode] if args.mode is not None else ['slab', 'batch']
+    failures = []
+    for mode in modes:
+        a = argv + ([] if args.mode is not None else ['--mode', mode])
+        log('bench: starting %d ranks (%s) as child processes ...' % (args.gpus, mode))
+        rc, lines, note = _spawn_ranks(args.gpus, a, args.launch_timeout, script)
+        js = [l for l in lines if l.startswith('{')]
+        if rc == 0 and js:
+            line = js[-1]
+            try:
+                j = json.loads(line)
+                j['launcher'] = dict(kind='self-launched child ranks (python bench.py --gpus %d)' % args.gpus, mode=mode, failed_attempts=failures)
+                line = json.dumps(j)
+            except ValueError:
+                pass
+            print(line, flush=True)
+            return 0
+        failures.append(dict(mode=mode, status=rc, note=note))
+        log('bench: the %s attempt failed (status %s%s)' % (mode, rc, ', ' + note if note else ''))
+    return failures[-1]['status'] or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -146,19 +263,24 @@ def main():
                     help='launch the FD and the spectral residual separately (3 launches) instead of the fused row pass (2 launches)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only to rehearse the multi-process path on a one-GPU box)")
-    ap.add_argument('--mode', choices=['batch', 'slab'], default='batch',
-                    help="batch: every rank owns --batch whole grids, no collective (weak scaling, default); "
-                         "slab: the SAME --batch grids are slab-decomposed by rows over the ranks -- RCCL halo "
-                         "send/recv for the stencil, 2 all-to-alls per spectral evaluation (strong scaling)")
+    ap.add_argument('--mode', choices=['batch', 'slab'], default=None,
+                    help="N > 1 only.  slab (default): the SAME --batch grids are slab-decomposed by rows over the ranks -- halo "
+                         "send/recv for the stencil, 2 all-to-alls per spectral evaluation (strong scaling); "
+                         "batch: every rank owns --batch whole grids, no data-path collective (weak scaling)")
+    ap.add_argument('--chunks', type=int, default=None, help='slab mode: batch chunks pipelined through the stages (default: 4 on RCCL, 1 on gloo)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` object (BASELINE configs 1, 2, 3, 5; ~20 s, N = 1 only)')
+    ap.add_argument('--launch-timeout', type=float, default=900.0, help='self-launcher: seconds before the child ranks are killed')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))                            # nothing has touched the GPU yet: `import torch` only
+    if args.mode is None:
+        args.mode = 'slab'
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py ..." % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     all_cores = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -195,9 +317,9 @@ def main():
         from nns.slab import SlabResidual
         nloc = n // world
         f = [t[:, rank * nloc:(rank + 1) * nloc].contiguous() for t in f]          # this rank's rows of every grid
-        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=prec)
+        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=prec, chunks=args.chunks)
 
-        def step():           # halo exchange under the two transposes + column pass, then ONE fused row pass (5-point stencil)
+        def step():           # per batch chunk: halo exchange under the two transposes + column pass, then ONE fused row pass (5-point stencil)
             sl.both(*f, stencil=args.stencil)
     else:
         out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
@@ -224,6 +346,46 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1 extras, measured after the timed region: what RCCL really saw, one un-pipelined evaluation phase by phase, and the
+    # embarrassingly parallel alternative (every rank its own --batch grids)
+    multi = None
+    if world > 1:
+        ones = torch.ones(1, device=device if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones)
+        multi = dict(transport=dict(backend=dist.get_backend(), library='RCCL (torch "nccl" on ROCm)' if args.backend == 'nccl' else
+                                    'gloo: device buffers staged through the host, every collective blocking (rehearsal only)',
+                                    device_buffers=args.backend == 'nccl'),
+                     rccl_ranks=int(ones.item()) if args.backend == 'nccl' else 0, ranks_confirmed_by_all_reduce=int(ones.item()))
+        if slab:
+            ph = slab_phases(sl, f, max(3, min(args.steps, 10)))
+            keys = sorted(ph)
+            t = torch.tensor([ph[k] for k in keys], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            multi['phases'] = dict(ms_max_over_ranks=dict(zip(keys, [float(x) for x in t.tolist()])), ms_rank0=ph,
+                                   note='ONE un-pipelined evaluation (chunks=1) with a device synchronisation after every phase; the timed step '
+                                        'pipelines %d batch chunks, so its time is less than the sum' % sl._nchunks(B))
+            a2a_bytes = 3.0 * B * (n // world) * n * 4 * (world - 1) / world       # bytes leaving this GPU per all-to-all
+            multi['comm'] = dict(all_to_all_bytes_leaving_each_gpu=a2a_bytes, all_to_alls_per_step=2, halo_bytes_sent_each_gpu=2 * 3.0 * B * n * 4,
+                                 chunks=sl._nchunks(B),
+                                 all_to_all_GBs_per_gpu={k: a2a_bytes / (multi['phases']['ms_max_over_ranks'][k] * 1e-3) / 1e9
+                                                         for k in ('all_to_all_1', 'all_to_all_2') if multi['phases']['ms_max_over_ranks'].get(k, 0) > 0})
+            # batch-sharded alternative: every rank evaluates its OWN --batch whole grids, no data-path collective
+            fb = make_inputs(B, n, args.distinct, 1234 + 1000 * rank, device)
+            ob1 = tuple(torch.empty_like(fb[0]) for _ in range(3)); ob2 = tuple(torch.empty_like(fb[0]) for _ in range(3))
+            for _ in range(min(args.warmup, 10)):
+                eng.both(*fb, out_fd=ob1, out_spec=ob2, stencil=args.stencil)
+            sync_all()
+            tb0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.both(*fb, out_fd=ob1, out_spec=ob2, stencil=args.stencil)
+            sync_all()
+            tb = torch.tensor([time.perf_counter() - tb0], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            multi['batch_sharded'] = dict(value=world * float(B) * n * n * args.steps / float(tb.item()), unit='residual-updates/s', scaling='weak',
+                                          ms_per_step=1e3 * float(tb.item()) / args.steps,
+                                          note='every rank its own %d grids, no data-path collective (not the headline: BASELINE config 4 is the slab decomposition)' % B)
+            del fb, ob1, ob2
 
     # grid 0 of the timed step's outputs, for the oracle check next to the CPU baseline (the per-kernel timing below reuses the buffers)
     check_out = [t[0].cpu().numpy() for t in (*out_fd, *out_sp)] if (rank == 0 and not slab and world == 1 and not args.no_cpu_baseline and args.stencil == 5) else None
@@ -320,12 +482,24 @@ def main():
                       data='synthetic',
                       config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral%s'
                                            % (n, n, B, args.stencil, ' (fused row pass: 2 launches)' if fused else ' (separate launches)'),
-                                  grid=[n, n], batch_per_gpu=B, parallelism=('row-slab x%d: RCCL halo send/recv + 2 all-to-all per spectral eval' % world) if slab else 'batch-sharded x%d (no data-path collective)' % world,
+                                  grid=[n, n], batch_per_gpu=B, global_batch=B if slab else B * world,
+                                  parallelism=('row-slab x%d: the same %d grids on all ranks; halo send/recv + 2 all-to-all transposes per evaluation over %s'
+                                               % (world, B, 'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)')) if slab
+                                  else 'batch-sharded x%d (no data-path collective)' % world,
                                   inputs='Taylor-Green t=0.1 + band-limited noise, nu=2pi/1000, dt=1e-3, resident in HBM'),
                       roofline=roofline)
+        if multi is not None:
+            result.update(multi)
     if dist is not None:
         dist.barrier()
     if rank == 0:
+        if world == 1 and not args.no_secondary:
+            log('bench: secondary configs (BASELINE configs 1, 2, 3, 5) ...')
+            try:
+                import bench_configs
+                result['secondary'] = bench_configs.secondary(cpu=not args.no_cpu_baseline)
+            except Exception as e:                                 # noqa: BLE001 -- an extra object: never lose the headline line over it
+                result['secondary'] = dict(error=repr(e))
         if not args.no_cpu_baseline and world == 1:
             log('bench: timing the NumPy oracle on the host (bounded sample) ...')
             result['cpu_baseline'] = cpu_baseline(n, check=check_out)

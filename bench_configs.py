@@ -78,7 +78,7 @@ def cpu_baseline_cfg1(n=64, nit=50, steps=2):
                 host_cores_present=os.cpu_count())
 
 
-def cpu_baseline_neural(K=10, n=51, nt=100):
+def cpu_baseline_neural(K=10, n=51, nt=100, budget_s=6.0):
     """spectral_ode.PDEFunc forward + backward on the host CPU with torch (float32, the reference's own shapes: 51 x 51, nt = 100,
     mb = 1; src/neural_spectral/spectral_ode.py:62-81,178-190) through the oracle's restatement."""
     from oracle import neural as ON
@@ -94,7 +94,7 @@ def cpu_baseline_neural(K=10, n=51, nt=100):
     def fwd_bwd():
         pred, _ = ON.pde_forward(init, mlp, basis, 1, nt)
         ON.loss_fn(pred, obs).backward()
-    t, reps = _cpu_time(fwd_bwd, budget_s=6.0, max_reps=5)
+    t, reps = _cpu_time(fwd_bwd, budget_s=budget_s, max_reps=5)
     return dict(value=1.0 / t, unit='training iterations/s (forward + backward)', cores=nth, kind='port', ms_per_iter=1e3 * t,
                 sample='%d x forward+backward of PDEFunc K=%d, %dx%d, nt=%d, mb=1, torch CPU float32 (%d threads)' % (reps, K, n, n, nt, nth),
                 host_cores_present=os.cpu_count())
@@ -202,6 +202,100 @@ def cfg5():
     tm = timeit(it, iters=3, warm=1)
     return dict(config='cfg5 ensemble 256 x 256x256 neural_spectral, K=10, nt=32, float32 (single GPU: all 256 members)',
                 fwd_bwd_ms=1e3 * tm, obs_GB=obs.numel() * 4 / 1e9, obs_stream_GBs=obs.numel() * 4 / tm / 1e9, note="observations are read ONCE per step (fused loss + gradient sweep)")
+
+
+HBM_PEAK_GBS, BF16_PEAK_TF, F32_PEAK_TF = 8000.0, 2500.0, 157.3          # MI355X_MICROARCH.md: HBM3E spec, dense bf16 MFMA, f32 vector = f32 MFMA
+
+
+def secondary(cpu=True):
+    """The other BASELINE.json configs under the same clock as the headline (bench.py appends this object to its JSON line; ~20 s):
+    cfg 1 step, cfg 2 training iteration, cfg 3 residual at 512^2 + depth-8 width-64 MLP forward / backward, cfg 5 step -- each with
+    the roofline that bounds it (`bound`, `achieved`, `peak`, `frac`, algorithmic bytes or FLOPs) and, where the reference has a CPU
+    path for it, the oracle port timed on this box's host (`cpu_baseline`, bounded samples)."""
+    from nns import ops
+    out = {}
+    # ---- cfg 1: chorin_fd 64 x 64 cavity, Re = 100, nit = 50, float64, explicit predictor (src/chorin_fd/simulate.py:212-234)
+    from nns.chorin_fd import NavierStokesSystem
+    from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+    n = 64
+    dx = dy = 2. / (n - 1)
+    u_bc = [D(0, 'left', dx, dy), D(1, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
+    v_bc = [D(0, 'left', dx, dy), D(0, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
+    p_bc = [D(0, 'top', dx, dy), N(0, 'bottom', dx, dy), N(0, 'left', dx, dy), N(0, 'right', dx, dy)]
+    z = np.zeros((n, n))
+    nt = 100
+    sysm = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=nt, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02, beta=1.25, method='explicit')
+    t1 = timeit(lambda: sysm.simulate_device(use_graph=False), iters=2, warm=1) / nt
+    S = 49                                                                  # at most nit - 1 sweeps (:183,:190)
+    b1 = (56 + 12 * S) * 2.0 * n * n                                        # SURVEY 8d: 56 + 12 S B/pt in float32, x 2 for float64
+    out['cfg1_chorin_fd_64_step'] = dict(ms=1e3 * t1, grid_point_steps_per_s=n * n / t1, dtype='f64', bound='latency (sequential SOR fronts of ONE 64^2 grid; HBM row for scale)',
+                                         algorithmic_bytes=b1, achieved=b1 / t1 / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=b1 / t1 / 1e9 / HBM_PEAK_GBS,
+                                         cpu_baseline=cpu_baseline_cfg1() if cpu else None)
+    # ---- cfg 2: neural_spectral 128 x 128, K = 10, nt = 100, mb = 1: one training iteration (src/neural_spectral/spectral_ode.py:178-190)
+    from nns.neural_spectral.spectral_ode import PDEFunc, PixelMLP
+    K, n, nt = 10, 128, 100
+    torch.manual_seed(0)
+    m = PDEFunc(K, n, n).cuda()
+    obs = torch.randn(nt, 1, 3, n, n, device='cuda')
+    t = torch.arange(nt, device='cuda') + 1
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    def it2():
+        opt.zero_grad()
+        m.loss(obs[0], t, obs).backward()
+        opt.step()
+    t2 = timeit(it2, iters=10, warm=3)
+    b2 = obs.numel() * 4.0
+    f2 = 3 * 4 * nt * 2.0 * (30 * 128 + 128 * 128 + 128 * 30)              # RK4, nt steps, forward + 2x backward, one trajectory
+    out['cfg2_neural_spectral_128_train_iter'] = dict(ms=1e3 * t2, iterations_per_s=1.0 / t2, dtype='f32', bound='latency (nt = 100 dependent RK4 steps of a 30-128-128-30 MLP; HBM row for scale)',
+                                                      algorithmic_bytes=b2, ode_flops=f2, achieved=b2 / t2 / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=b2 / t2 / 1e9 / HBM_PEAK_GBS,
+                                                      cpu_baseline=cpu_baseline_neural(budget_s=3.0) if cpu else None)
+    del m, obs, opt
+    # ---- cfg 3: 512 x 512, Re = 1000: residual (FD 5-point + spectral) of 64 grids; depth-8 width-64 MLP on 16 x 512^2 pixels, bf16 on MFMA
+    from nns.periodic import ResidualEngine
+    from nns.synthetic import residual_inputs
+    n, B = 512, 64
+    f = [torch.as_tensor(np.tile(a, (B // 4, 1, 1)), device='cuda') for a in residual_inputs(4, n)]
+    eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000)
+    o1 = tuple(torch.empty_like(f[0]) for _ in range(3)); o2 = tuple(torch.empty_like(f[0]) for _ in range(3))
+    t3 = timeit(lambda: eng.both(*f, out_fd=o1, out_spec=o2), iters=20, warm=5)
+    b3 = 80.0 * B * n * n
+    out['cfg3_residual_512'] = dict(ms=1e3 * t3, residual_updates_per_s=B * n * n / t3, dtype='f32', bound='hbm', bytes_per_pt_two_pass=80.0, algorithmic_bytes=b3,
+                                    achieved=b3 / t3 / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=b3 / t3 / 1e9 / HBM_PEAK_GBS)
+    del f, o1, o2
+    mlp = PixelMLP(8, 64).cuda()
+    x = torch.randn(16, 3, n, n, device='cuda')
+    flops = 2.0 * 16 * n * n * (3 * 64 + 6 * 64 * 64 + 64 * 3)
+    with torch.no_grad():
+        tf = timeit(lambda: mlp(x, bf16=True), iters=10, warm=3)
+        tf32 = timeit(lambda: mlp(x, bf16=False), iters=5, warm=2)
+    gy = torch.randn_like(x)
+    ws, bs = [w.detach() for w in mlp.weights], [b.detach() for b in mlp.biases]
+    tb = timeit(lambda: ops.pixel_mlp_bwd(x, gy, ws, bs), iters=10, warm=3)
+    out['cfg3_mlp_d8_w64_forward_bf16'] = dict(ms=1e3 * tf, dtype='bf16 (f32 accumulate)', bound='mfma', useful_flops=flops, achieved=flops / tf / 1e12, peak=BF16_PEAK_TF,
+                                              unit='TFLOP/s', frac=flops / tf / 1e12 / BF16_PEAK_TF)
+    out['cfg3_mlp_d8_w64_forward_f32'] = dict(ms=1e3 * tf32, dtype='f32', bound='mfma', useful_flops=flops, achieved=flops / tf32 / 1e12, peak=F32_PEAK_TF, unit='TFLOP/s',
+                                             frac=flops / tf32 / 1e12 / F32_PEAK_TF)
+    out['cfg3_mlp_d8_w64_backward_bf16'] = dict(ms=1e3 * tb, dtype='bf16 (f32 accumulate)', bound='mfma', useful_flops=3 * flops, achieved=3 * flops / tb / 1e12, peak=BF16_PEAK_TF,
+                                               unit='TFLOP/s', frac=3 * flops / tb / 1e12 / BF16_PEAK_TF,
+                                               note='forward recompute + data chain + weight gradients = 3x the forward FLOPs, one launch, no saved activations')
+    del mlp, x, gy
+    # ---- cfg 5: ensemble of 256 initial conditions x 256^2, K = 10, nt = 32: loss + backward of one step on ONE GPU (all 256 members)
+    K, n, nt, mb = 10, 256, 32, 256
+    m = PDEFunc(K, n, n).cuda()
+    obs = torch.randn(nt, mb, 3, n, n, device='cuda')                       # 6.4 GB
+    t = torch.arange(nt, device='cuda') + 1
+
+    def it5():
+        m.zero_grad()
+        m.loss(obs[0], t, obs).backward()
+    t5 = timeit(it5, iters=4, warm=2)
+    b5 = obs.numel() * 4.0
+    out['cfg5_ensemble_256x256_step'] = dict(ms=1e3 * t5, dtype='f32', bound='hbm', algorithmic_bytes=b5, achieved=b5 / t5 / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                                             frac=b5 / t5 / 1e9 / HBM_PEAK_GBS, note='forward + backward; the 6.4 GB of observations cross HBM once per step (fused loss + gradient sweep)')
+    del m, obs
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_ops():

@@ -864,7 +864,12 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
 #ifndef NNS_XPASS_SPLIT
 #define NNS_XPASS_SPLIT 1          // 1: spec_xpass_split_kernel (8 transform waves + 4 memory waves), 0: spec_xpass_kernel
 #endif
-    if constexpr (NNS_XPASS_SPLIT) {
+    // the role-split kernel's memory waves address with a scalar grid base + a 32-BIT element offset per lane: the largest offset inside
+    // one grid (SEG: across all source-rank segments) must stay below 2^32; beyond that the older kernel (size_t row offsets) takes over
+    const unsigned long long max_off = SEG ? (unsigned long long)((N >> sg.shift) - 1) * (unsigned long long)sg.stride + ((unsigned long long)ny << sg.shift)
+                                           : (unsigned long long)N * (unsigned long long)ny;
+    const bool off32_ok = max_off < (1ull << 32);
+    if (NNS_XPASS_SPLIT && off32_ok) {
         auto kern = spec_xpass_split_kernel<N, TF, SEG>;
         using SL = SplitLds<N, TF>;
         static bool attr_set = false;

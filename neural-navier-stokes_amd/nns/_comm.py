@@ -8,7 +8,15 @@
 
 xGMI is point-to-point: a halo exchange talks to the two ring neighbours only (their two direct links); the transpose is ONE
 all-to-all (all seven links of a GPU at once).
+
+STATUS of the "nccl" branch: a one-GPU lease cannot hold two RCCL ranks, so what has run on hardware is (a) the world-1 LOOPBACK
+form (`Transport(loopback=True)` or NNS_COMM_LOOPBACK=1: a rank's messages to "its neighbours" and its all-to-all go through the
+RCCL process group to itself -- device buffers, grouped send/recv, async all_to_all_single, stream-ordered wait(), the int-view
+all-reduce -- tests/test_gpu_rccl_loopback.py) and (b) every multi-rank path on the gloo-staged branch.  Transfers between two
+GPUs over xGMI, and the overlap they allow, are first exercised by the driver's multi-GPU bench.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -28,11 +36,20 @@ class _Works(object):
 
 
 class Transport(object):
-    def __init__(self, group=None):
+    def __init__(self, group=None, loopback=None):
         self.group = group
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else 'none'
+        # loopback: with ONE rank, still send every message through the process group (to this rank itself) instead of the local copy
+        if loopback is None:
+            loopback = os.environ.get('NNS_COMM_LOOPBACK', '0') == '1'
+        self.loopback = bool(loopback) and self.P == 1 and dist.is_initialized()
+
+    @property
+    def local(self):
+        """True when there is nobody to talk to (one rank, no loopback): messages are local copies."""
+        return self.P == 1 and not self.loopback
 
     def _staged(self, t):
         return t.is_cuda and self.backend != 'nccl'
@@ -42,7 +59,7 @@ class Transport(object):
         """sends / recvs: lists of (tensor, peer) in POSTING ORDER (two messages between one pair of ranks are matched in
         that order -- with two ranks both ring neighbours are the same peer).  Returns a handle; the receive buffers are
         valid after handle.wait()."""
-        if self.P == 1 or not (sends or recvs):
+        if self.local or not (sends or recvs):
             return _Done()
         if any(self._staged(t) for t, _ in sends + recvs):
             hs = [(t.cpu(), peer) for t, peer in sends]
@@ -61,7 +78,7 @@ class Transport(object):
         rank's `first`, from_up the previous rank's `last`.  wrap=False: the ends of the chain have no neighbour there
         (pass None for the buffers that do not exist)."""
         P, r = self.P, self.rank
-        if P == 1:
+        if self.local:
             if wrap:
                 from_up.copy_(last), from_down.copy_(first)
             return _Done()
@@ -82,7 +99,7 @@ class Transport(object):
     # ------------------------------------------------------------------ collectives
     def all_to_all(self, recv, send):
         """recv[src] <- rank src's send[this rank] (equal splits along dim 0)."""
-        if self.P == 1:
+        if self.local:
             recv.copy_(send)
             return _Done()
         if self._staged(send):
@@ -96,7 +113,7 @@ class Transport(object):
 
     def all_reduce_(self, t, op):
         """In place, stream-ordered on nccl (no host synchronisation)."""
-        if self.P == 1:
+        if self.local:
             return t
         if self._staged(t):
             h = t.cpu()

@@ -1,33 +1,36 @@
-"""Black-box next-frame baseline (reference: src/neural_spectral/rnn.py:13-40): a GRU over
-flattened (u, v, p) frames followed by a two-layer MLP.  A comparison baseline, kept on torch modules (MIOpen GRU,
-rocBLAS linears) -- nothing here is on the residual hot path.  Same class surface and state-dict names as the reference;
-`forward` reshapes instead of `.view`, so batches larger than 1 work too (the reference's `.view` fails on them)."""
+"""Black-box next-frame baseline with the reference's class surface (src/neural_spectral/rnn.py:13-40; SURVEY.md section 8 (f)
+rank 4): a GRU over flattened (u, v, p) frames and a two-layer read-out.  A comparison baseline on torch modules (MIOpen GRU,
+rocBLAS linears) -- nothing here is on the residual hot path.  What this file owns is the state-dict contract (`gru.*`,
+`linear.0.*`, `linear.2.*`, so reference checkpoints load with strict=True) and batch-safe shapes: the read-out is applied
+to the [mb, nt, hidden] sequence as it stands (the reference flattens with a `.view` that only works for mb = 1), and the
+roll-out writes into one preallocated host tensor."""
 import torch
-import torch.nn as nn
+from torch import nn
+
+
+def _readout(hidden, frame):
+    return nn.Sequential(nn.Linear(hidden, hidden), nn.ReLU(), nn.Linear(hidden, frame))
 
 
 class RNN(nn.Module):
     def __init__(self, input_dim, hidden_dim=256):
         super().__init__()
-        self.input_dim = input_dim
-        self.hidden_dim = hidden_dim
-        self.gru = nn.GRU(self.input_dim, self.hidden_dim, batch_first=True)
-        self.linear = nn.Sequential(
-            nn.Linear(self.hidden_dim, self.hidden_dim),
-            nn.ReLU(),
-            nn.Linear(self.hidden_dim, self.input_dim))
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.gru = nn.GRU(input_dim, hidden_dim, batch_first=True)
+        self.linear = _readout(hidden_dim, input_dim)
 
     def forward(self, obs_seq):
-        mb, nt = obs_seq.size(0), obs_seq.size(1)
-        out_seq, gru_hid = self.gru(obs_seq, None)
-        out_seq = self.linear(out_seq.reshape(mb * nt, -1))
-        return out_seq.view(mb, nt, -1), gru_hid
+        """obs_seq [mb, nt, input_dim] -> (next-frame predictions [mb, nt, input_dim], final hidden state [1, mb, hidden])."""
+        states, last = self.gru(obs_seq)
+        return self.linear(states), last
 
+    @torch.no_grad()
     def extrapolate(self, obs, T_extrapolate):
-        h0 = None
-        out_extrapolate = []
-        for _ in range(T_extrapolate):
-            out, h0 = self.gru(obs, h0)
-            obs = self.linear(out.squeeze(1)).unsqueeze(1)
-            out_extrapolate.append(obs.cpu().detach())
-        return torch.cat(out_extrapolate, dim=1)
+        """Autoregressive roll-out from the frame(s) obs [mb, 1, input_dim]: [mb, T_extrapolate, input_dim] on the host."""
+        frames = torch.empty(obs.size(0), T_extrapolate, self.input_dim, dtype=obs.dtype)
+        frame, hidden = obs, None
+        for k in range(T_extrapolate):
+            state, hidden = self.gru(frame, hidden)
+            frame = self.linear(state)
+            frames[:, k] = frame[:, 0].cpu()
+        return frames

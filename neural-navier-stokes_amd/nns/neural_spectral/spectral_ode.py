@@ -149,20 +149,13 @@ class PDEFunc(nn.Module):
         return basis_sumsq(coeff, basis, o)
 
     def basis_weight_mat(self):
-        W = []
-        for k in range(self.K):
-            theta = self.basis_fns[k].flatten()
-            W.append(theta)
-        return torch.stack(W)
+        """[K, 3 nx ny]: one flattened basis function per row (spectral_ode.py:83-88)."""
+        return torch.stack([f.reshape(-1) for f in self.basis_fns])
 
     def diversity_penalty(self):
-        W = self.basis_weight_mat()
-        penalty = 0
-        for i in range(0, self.K):
-            for j in range(i, self.K):
-                penalty = penalty + torch.norm(W[i] - W[j], p=2)
-        penalty = 1. / penalty
-        return penalty
+        """1 / sum of pairwise L2 distances between the basis functions (spectral_ode.py:90-97; logging only, :184-186).  The
+        reference's double loop also visits i == j, whose distance is zero: the sum over pairs i < j is the same number."""
+        return 1. / torch.pdist(self.basis_weight_mat(), p=2).sum()
 
 
 class BasisFunc(nn.Module):
@@ -216,19 +209,15 @@ class PixelMLP(nn.Module):
 
 
 class AverageMeter(object):
-    """Computes and stores the average and current value (spectral_ode.py:122-137)."""
+    """Running weighted mean of a logged scalar, with the attribute names the training loop reads (`val`, `sum`, `count`,
+    `avg`; spectral_ode.py:122-137)."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self.val = self.sum = self.count = self.avg = 0
 
     def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
+        self.val, self.sum, self.count = val, self.sum + val * n, self.count + n
         self.avg = self.sum / self.count

@@ -22,14 +22,12 @@ class PDEFunc(nn.Module):
         ])
 
     def rnnint(self, init_coeff, nt):
-        """:35-43: the GRU is fed its own output, one step at a time; returns [nt * mb, K*3]."""
-        inputs = init_coeff.unsqueeze(1)
-        h0 = None
-        coeff = []
+        """The GRU fed its own output for nt steps from init_coeff [mb, K*3] (:35-43); returns the steps stacked as [nt * mb, K*3]."""
+        x, h, steps = init_coeff[:, None, :], None, []
         for _ in range(nt):
-            inputs, h0 = self.basis_coeffs(inputs, h0)
-            coeff.append(inputs.squeeze(1))
-        return torch.cat(coeff)
+            x, h = self.basis_coeffs(x, h)
+            steps.append(x[:, 0])
+        return torch.cat(steps)
 
     def _coeff(self, mb, nt):
         return self.rnnint(self.init_coeffs.unsqueeze(0).repeat(mb, 1), nt).view(nt * mb, self.K, 3)      # (:52) view(nt, mb, K, 3)
@@ -50,12 +48,7 @@ class PDEFunc(nn.Module):
         return _BasisLossFn.apply(coeff, basis, o)
 
     def basis_weight_mat(self):
-        return torch.stack([self.basis_fns[k].flatten() for k in range(self.K)])
+        return torch.stack([f.reshape(-1) for f in self.basis_fns])
 
     def diversity_penalty(self):
-        W = self.basis_weight_mat()
-        penalty = 0
-        for i in range(0, self.K):
-            for j in range(i, self.K):
-                penalty = penalty + torch.norm(W[i] - W[j], p=2)
-        return 1. / penalty
+        return 1. / torch.pdist(self.basis_weight_mat(), p=2).sum()

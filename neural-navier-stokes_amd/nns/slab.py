@@ -63,14 +63,17 @@ class HipCompute(object):
         from . import ops
         return ops.spec_residual_ypass_(u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise)
 
-    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise):
+    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None):
         from . import ops
-        return ops.residual_both_rowpass_halo(u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise)
+        return ops.residual_both_rowpass_halo(u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=out_fd)
 
 
 class SlabResidual(object):
-    def __init__(self, nx, ny, dt, rho, nu, Lx=2 * math.pi, Ly=2 * math.pi, group=None, compute=None, precise=True):
-        self.tr = Transport(group)
+    def __init__(self, nx, ny, dt, rho, nu, Lx=2 * math.pi, Ly=2 * math.pi, group=None, compute=None, precise=True, chunks=None, loopback=None):
+        """chunks: how many batch chunks `both` / `spectral` pipeline through their stages (None: 4 on a stream-ordered transport
+        with more than one rank, 1 otherwise -- see `_pipeline`)."""
+        self.tr = Transport(group, loopback=loopback)
+        self.chunks = chunks
         self.group, self.P, self.rank = group, self.tr.P, self.tr.rank
         if nx % self.P or ny % self.P:
             raise ValueError("nx and ny must be divisible by the number of ranks (%d x %d over %d)" % (nx, ny, self.P))
@@ -92,15 +95,15 @@ class SlabResidual(object):
         return b
 
     # ------------------------------------------------------------------ FD: halo rows
-    def start_halo(self, fields):
+    def start_halo(self, fields, tag=0):
         """fields: list of F [B, nloc, ny] row slabs.  Packs their first / last rows (ONE launch each) and starts the ring
         exchange.  Returns (handle, top, bot): after handle.wait(), top / bot [F, B, ny] hold row -1 / row nloc of the slab
-        (the periodic neighbours' edge rows)."""
+        (the periodic neighbours' edge rows).  tag: which set of message buffers to use (one per exchange in flight)."""
         f0 = fields[0]
         B, nloc, ny = f0.shape
         F = len(fields)
-        first, last = self._buf('first', (F, B, ny), f0), self._buf('last', (F, B, ny), f0)
-        top, bot = self._buf('top', (F, B, ny), f0), self._buf('bot', (F, B, ny), f0)
+        first, last = self._buf(('first', tag), (F, B, ny), f0), self._buf(('last', tag), (F, B, ny), f0)
+        top, bot = self._buf(('top', tag), (F, B, ny), f0), self._buf(('bot', tag), (F, B, ny), f0)
         c = self.compute
         c.gather_lines(fields, first, B, nloc * ny, 0, ny)
         c.gather_lines(fields, last, B, nloc * ny, (nloc - 1) * ny, ny)
@@ -118,35 +121,91 @@ class SlabResidual(object):
         return out
 
     # ------------------------------------------------------------------ spectral: all-to-all transpose
-    def _xpass_partials(self, u, v, p):
-        """Row slabs u, v, p -> the column pass's three partials as row slabs (2 all-to-alls, 2 copy kernels)."""
+    def _nchunks(self, B, chunks=None):
+        c = chunks if chunks is not None else self.chunks
+        if c is None:
+            # a stream-ordered transport overlaps chunk c+1's transfers with chunk c's kernels; a staged (blocking) one gains nothing
+            c = 4 if (self.tr.backend == 'nccl' and not self.tr.local) else 1
+        return max(1, min(int(c), B))
+
+    def _pipeline(self, u, v, p, finish, chunks=None):
+        """The spectral path's three stages, software-pipelined over chunks of the batch axis (independent grids):
+
+            stage 0 (chunk c):  pack row slabs -> send buffer [dest][u, v, p][Bc][nloc][ny/P];  start all-to-all #1
+            stage 1 (chunk c):  wait #1;  column pass on the receive buffer in place -> return buffer;  start all-to-all #2
+            stage 2 (chunk c):  wait #2;  scatter the returned blocks into row slabs;  finish(c, rows, partials)  [the row pass]
+
+        enqueued in the order s0(c), s1(c-1), s2(c-2) per tick, so that on a stream-ordered transport (RCCL) the collectives run
+        back to back on the communication stream -- #1(0), #1(1), #2(0), #1(2), #2(1), ... -- while the compute stream packs,
+        transforms and finishes other chunks: the links stay busy and all but the first pack / last row pass hide under them.
+        Every kernel treats grids independently, so the results do not depend on the chunking (checked bitwise in the tests).
+        finish(c, sl, parts): sl = the chunk's batch slice, parts = its three partial fields as row slabs."""
         B, nloc, ny = u.shape
-        P, nyl, c = self.P, self.nyloc, self.compute
-        shape = (P, 3, B, nloc, nyl)
-        send, recv = self._buf('a2a_s1', shape, u), self._buf('a2a_r1', shape, u)
-        c.transpose_pack([u, v, p], send, P)
-        self.tr.all_to_all(recv, send).wait()
-        back = self._buf('a2a_s2', shape, u)
-        c.spec_xpass_seg(recv, back, B, self.nx, nyl, nloc, self.Lx, self.rho, self.nu, self.precise)
-        got = self._buf('a2a_r2', shape, u)
-        self.tr.all_to_all(got, back).wait()
-        parts = [torch.empty_like(u) for _ in range(3)]
-        c.transpose_unpack(got, parts, P)
-        return parts
+        P, nyl, c_ = self.P, self.nyloc, self.compute
+        C = self._nchunks(B, chunks)
+        bounds = [(B * c // C, B * (c + 1) // C) for c in range(C)]
+        st = [None] * C
+        parts_full = [torch.empty_like(u) for _ in range(3)]
 
-    def spectral(self, u, v, p, u_prev, v_prev):
-        ru, rv, rd = self._xpass_partials(u, v, p)
-        return self.compute.spec_ypass(u, v, p, u_prev, v_prev, ru, rv, rd, self.dt, self.Ly, self.rho, self.nu, self.precise)
+        def s0(c):
+            sl = slice(*bounds[c])
+            f = [t[sl] for t in (u, v, p)]
+            shape = (P, 3, f[0].shape[0], nloc, nyl)
+            send, recv = self._buf(('a2a_s1', c), shape, u), self._buf(('a2a_r1', c), shape, u)
+            c_.transpose_pack(f, send, P)
+            st[c] = dict(sl=sl, shape=shape, recv=recv, h1=self.tr.all_to_all(recv, send))
 
-    def both(self, u, v, p, u_prev, v_prev, stencil=5):
-        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- the halo exchange travels
-        under the transposes and the column pass, then ONE row pass does the stencil and finishes the spectral residual."""
+        def s1(c):
+            d = st[c]
+            d['h1'].wait()
+            back, got = self._buf(('a2a_s2', c), d['shape'], u), self._buf(('a2a_r2', c), d['shape'], u)
+            c_.spec_xpass_seg(d['recv'], back, d['shape'][2], self.nx, nyl, nloc, self.Lx, self.rho, self.nu, self.precise)
+            d['got'], d['h2'] = got, self.tr.all_to_all(got, back)
+
+        def s2(c):
+            d = st[c]
+            d['h2'].wait()
+            parts = [t[d['sl']] for t in parts_full]
+            c_.transpose_unpack(d['got'], parts, P)
+            finish(c, d['sl'], parts)
+
+        for tick in range(C + 2):
+            if tick < C:
+                s0(tick)
+            if 0 <= tick - 1 < C:
+                s1(tick - 1)
+            if 0 <= tick - 2 < C:
+                s2(tick - 2)
+        return parts_full
+
+    def _xpass_partials(self, u, v, p, chunks=None):
+        """Row slabs u, v, p -> the column pass's three partials as row slabs (2 all-to-alls, 2 copy kernels per chunk)."""
+        return self._pipeline(u, v, p, lambda c, sl, parts: None, chunks)
+
+    def spectral(self, u, v, p, u_prev, v_prev, chunks=None):
+        c_ = self.compute
+        fin = lambda c, sl, parts: c_.spec_ypass(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], *parts, self.dt, self.Ly, self.rho, self.nu, self.precise)
+        return tuple(self._pipeline(u, v, p, fin, chunks))
+
+    def both(self, u, v, p, u_prev, v_prev, stencil=5, chunks=None):
+        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- per batch chunk the halo exchange
+        travels under the transposes and the column pass, then ONE row pass does the stencil and finishes the spectral residual;
+        the chunks are pipelined (`_pipeline`)."""
         if stencil != 5 or u.dtype not in getattr(self.compute, 'fused_dtypes', (torch.float32,)):
-            return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev)
-        h, top, bot = self.start_halo([u, v, p])
-        parts = self._xpass_partials(u, v, p)
-        h.wait()
-        return self.compute.both_rowpass_halo(u, v, p, u_prev, v_prev, top, bot, parts, self.dt, self.dx, self.Ly, self.rho, self.nu, self.precise)
+            return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev, chunks)
+        B = u.shape[0]
+        C = self._nchunks(B, chunks)
+        # the halo messages of every chunk leave first: tiny, and the row pass of chunk c needs them two ticks later
+        halos = [self.start_halo([t[B * c // C:B * (c + 1) // C] for t in (u, v, p)], tag=c) for c in range(C)]
+        out_fd = tuple(torch.empty_like(u) for _ in range(3))
+
+        def fin(c, sl, parts):
+            h, top, bot = halos[c]
+            h.wait()
+            self.compute.both_rowpass_halo(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], top, bot, parts, self.dt, self.dx, self.Ly, self.rho, self.nu,
+                                           self.precise, out_fd=tuple(t[sl] for t in out_fd))
+        parts = self._pipeline(u, v, p, fin, C)
+        return out_fd, tuple(parts)
 
 
 class HipSorCompute(object):

@@ -28,7 +28,53 @@ def rank_residual(rank, world):
     bf, bs = s.both(*loc)
     for i in range(3):
         res['bfd_%d' % i], res['bspec_%d' % i] = bf[i].cpu().numpy(), bs[i].cpu().numpy()
+    # back-to-back calls reuse the message buffers; the batch-chunk pipeline (the default on RCCL) must not change a bit
+    for chunks in (1, 2, 2):
+        bf2, bs2 = s.both(*loc, chunks=chunks)
+        sp2 = s.spectral(*loc, chunks=chunks)
+        for i in range(3):
+            assert torch.equal(bf2[i], bf[i]) and torch.equal(bs2[i], bs[i]), ('both', chunks, i)
+            assert np.array_equal(sp2[i].cpu().numpy(), res['spec_%d' % i]), ('spectral', chunks, i)
     return res
+
+
+def rank_loopback(rank, world):
+    """World-1 RCCL LOOPBACK (nns/_comm.py): every message of the slab paths goes through the RCCL process group to this rank
+    itself -- grouped send/recv on device buffers with both ring neighbours the same peer, async all_to_all_single, stream-ordered
+    wait(), the integer-view all-reduce(MAX) -- and the results must be bitwise the single-process kernels'."""
+    import torch.distributed as dist
+    from nns import ops
+    from nns.slab import SlabResidual
+    from nns._comm import Transport
+    assert world == 1 and dist.get_backend() == 'nccl'
+    f = residual_fields()
+    d = [torch.as_tensor(a, device='cuda') for a in f]
+    s = SlabResidual(N, N, DT, RHO, NU, L, L, loopback=True)
+    assert s.tr.loopback and not s.tr.local
+    h = L / N
+    ref = {5: ops.fd_residual(*d, DT, h, h, RHO, NU, 5), 9: ops.fd_residual(*d, DT, h, h, RHO, NU, 9)}
+    ref_sp = ops.spec_residual(*d, DT, L, L, RHO, NU)
+    ref_bfd, ref_bsp = ops.residual_both(*d, DT, L, L, RHO, NU)
+    checks = 0
+    for rep in range(3):                                        # back to back: the message buffers are reused
+        for st in (5, 9):
+            for a, b in zip(s.fd(*d, stencil=st), ref[st]):
+                assert torch.equal(a, b), ('fd', st, rep)
+        for chunks in (1, 2):
+            for a, b in zip(s.spectral(*d, chunks=chunks), ref_sp):
+                assert torch.equal(a, b), ('spectral', chunks, rep)
+            bf, bs = s.both(*d, chunks=chunks)
+            for a, b in zip(list(bf) + list(bs), list(ref_bfd) + list(ref_bsp)):
+                assert torch.equal(a, b), ('both', chunks, rep)
+            checks += 1
+    # the SOR error slots travel as an integer view through all-reduce(MAX) (nns/slab.py SlabPressure.solve_slab_)
+    tr = Transport(loopback=True)
+    slots = torch.tensor([1.0, 0.25, float('nan'), 0.0], device='cuda')
+    before = slots.clone()
+    tr.all_reduce_(slots.view(torch.int32)[1:3], dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    assert torch.equal(slots.view(torch.int32), before.view(torch.int32))
+    return dict(checks=np.array(checks))
 
 
 # ---- the chorin_fd cavity step sharded over ranks (float64: bitwise) -----------------------------------------------

@@ -61,10 +61,12 @@ class OracleCompute(OracleLines):
 
     def spec_ypass(self, u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise):
         r = OP.spectral_ypart(*[t.numpy() for t in (u, v, p, up, vp, ru, rv, rd)], dt, Ly, rho, nu)
-        return tuple(_t(a) for a in r)
+        for o, a in zip((ru, rv, rd), r):                    # in place, as nns_spec_residual_ypass_f32 finishes the partials
+            o.copy_(_t(a))
+        return ru, rv, rd
 
-    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise):
-        fd = tuple(torch.empty_like(u) for _ in range(3))
+    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None):
+        fd = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
         self.fd_residual_halo(u, v, p, up, vp, top, bot, dt, dx, Ly / u.shape[2], rho, nu, 5, None, fd)
         return fd, self.spec_ypass(u, v, p, up, vp, *partials, dt, Ly, rho, nu, precise)
 

@@ -24,19 +24,20 @@ pytestmark = pytest.mark.gpu
 WORLD = 2
 
 
-def run_ranks(case, out, world=WORLD):
+def run_ranks(case, out, world=WORLD, backend="gloo", device="0", timeout=600):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   MR_BACKEND=backend, MR_DEVICE=device)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'mr_worker.py'), case, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -47,12 +48,16 @@ def run_ranks(case, out, world=WORLD):
     return [np.load(os.path.join(out, '%s_r%d.npz' % (case, r))) for r in range(world)]
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_slab_residual_two_ranks_hip_1024(world, tmp_path, gpu_device):
-    """(world = 4: each rank has TWO distinct ring neighbours and three all-to-all peers; at most 6 processes may share the card.)"""
+def test_rccl_world1_loopback_slab_paths_bitwise(tmp_path, gpu_device):
+    """The RCCL branch of the transport on the hardware a one-GPU box offers: ONE rank whose messages go through the RCCL process
+    group to itself (tests/mr_cases.py rank_loopback)."""
+    parts = run_ranks("loopback", str(tmp_path), world=1, backend="nccl", timeout=300)
+    assert int(parts[0]['checks']) == 6
+
+
+def _check_slab_residual(parts):
     from nns import ops
     from oracle import periodic as OP
-    parts = run_ranks('residual', str(tmp_path), world)
     f = MC.residual_fields()
     d = [torch.as_tensor(a, device='cuda') for a in f]
     h = MC.L / MC.N
@@ -72,12 +77,35 @@ def test_slab_residual_two_ranks_hip_1024(world, tmp_path, gpu_device):
             assert np.array_equal(got[i], single[key][i].cpu().numpy()), '%s[%d]: two-rank slab result differs from the single-process kernel' % (key, i)
 
 
+@pytest.mark.parametrize('world', [2, 4])
+def test_slab_residual_two_ranks_hip_1024(world, tmp_path, gpu_device):
+    """(world = 4: each rank has TWO distinct ring neighbours and three all-to-all peers; at most 6 processes may share the card.)"""
+    _check_slab_residual(run_ranks('residual', str(tmp_path), world))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per GPU (a one-GPU box runs the loopback and gloo forms)")
+def test_slab_residual_two_ranks_rccl_1024(tmp_path, gpu_device):
+    """The same checks with the transport on RCCL, one rank per GPU (device buffers, grouped send/recv, async all-to-all with
+    stream-ordered waits, the batch-chunk pipeline; P = 2: both ring neighbours are the same peer)."""
+    _check_slab_residual(run_ranks('residual', str(tmp_path), 2, backend='nccl', device='rank'))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per GPU")
+def test_slab_chorin_two_ranks_rccl_bitwise(tmp_path, gpu_device):
+    """SlabChorinFD / SlabPressure on RCCL: halo exchange per half-sweep, int-view all-reduce(MAX) of the error slots."""
+    _check_slab_chorin(run_ranks('chorin96', str(tmp_path), 2, backend='nccl', device='rank'), 96)
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_slab_chorin_two_ranks_hip_bitwise(world, tmp_path, gpu_device):
     """(world = 3: uneven 96 = 32 + 32 + 32 rows is even, so the cavity is 98 wide there: 33 + 33 + 32, and the middle rank owns no wall.)"""
+    n = 96 if world == 2 else 98
+    _check_slab_chorin(run_ranks('chorin%d' % n, str(tmp_path), world), n)
+
+
+def _check_slab_chorin(parts, n):
     from nns.chorin_fd import NavierStokesSystem
-    MC.CN = 96 if world == 2 else 98
-    parts = run_ranks('chorin%d' % MC.CN, str(tmp_path), world)
+    MC.CN = n
     ics, (u_bc, v_bc, p_bc) = MC.cavity_problem()
     for method, axis in (('explicit', 1), ('semi_implicit', 2)):
         s = NavierStokesSystem(*[a.copy() for a in ics], u_bc, v_bc, p_bc, nt=MC.CNT, nit=MC.CNIT, nx=MC.CN, ny=MC.CN, dt=1e-3, rho=1.0, nu=0.05,

@@ -67,21 +67,23 @@ def test_fd_residual_ragged_sizes_both_paths(shape, gpu_device):
 
 
 @pytest.mark.parametrize('n', [64, 128, 256, 512, 1024])
-def test_spectral_residual_vs_oracle(n, gpu_device):
+@pytest.mark.parametrize('precise', [0, 1, 2])
+def test_spectral_residual_vs_oracle(n, precise, gpu_device):
+    """All three arithmetic policies at all five sizes, held to the north star's 1e-5: 0 = all-float32 transforms of
+    forward-differenced lines (the mode the headline runs in; its viscous amplification nu pi N / (sqrt(3) L) is 1.86 at
+    N = 1024 here, far under the bound of 8 the automatic policy applies), 1 = the library picks, 2 = float64 forward transforms."""
     from nns import ops
     from oracle import periodic as OP
+    assert NU * np.pi * n / (np.sqrt(3) * L) <= 8
     f = inputs(2, n)
-    got = host(ops.spec_residual(*[dev(a) for a in f], DT, L, L, RHO, NU, precise=True))
+    got = host(ops.spec_residual(*[dev(a) for a in f], DT, L, L, RHO, NU, precise=precise))
     ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], DT, L, L, RHO, NU)
     for g, r in zip(got, ref):
         assert rel_l2(g, r) <= TOL
-    # the all-float32 fast mode is documented at ~2e-4 (forward rounding noise amplified by k)
-    fast = host(ops.spec_residual(*[dev(a) for a in f], DT, L, L, RHO, NU, precise=False))
-    for g, r in zip(fast, ref):
-        assert rel_l2(g, r) <= 2e-3
 
 
-def test_spectral_residual_non_square_and_box_lengths(gpu_device):
+@pytest.mark.parametrize('precise', [0, 1, 2])
+def test_spectral_residual_non_square_and_box_lengths(precise, gpu_device):
     from nns import ops
     from oracle import periodic as OP
     rng = np.random.default_rng(8)
@@ -92,7 +94,7 @@ def test_spectral_residual_non_square_and_box_lengths(gpu_device):
                   0.01 * rng.standard_normal((nx, ny))).astype(np.float32)[None]
     f = [mk() for _ in range(5)]
     Lx, Ly = 1.5, 4.0
-    got = host(ops.spec_residual(*[dev(a) for a in f], 2e-3, Lx, Ly, 1.2, 0.01))
+    got = host(ops.spec_residual(*[dev(a) for a in f], 2e-3, Lx, Ly, 1.2, 0.01, precise=precise))
     ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], 2e-3, Lx, Ly, 1.2, 0.01)
     for g, r in zip(got, ref):
         assert rel_l2(g, r) <= TOL
@@ -451,19 +453,21 @@ def test_marching_row_pass_equals_separate_kernels(B, nx, ny, gpu_device):
         assert rel_l2(fo[k][B - 1].cpu().numpy(), ref_fd[k]) <= TOL and rel_l2(so[k][B - 1].cpu().numpy(), ref_sp[k]) <= TOL
 
 
-def test_marching_row_pass_on_a_row_slab(gpu_device):
+@pytest.mark.parametrize('precise', [0, 2])
+def test_marching_row_pass_on_a_row_slab(precise, gpu_device):
     """The marching row pass on a row slab (nx_local = 44 rows: chunks of 8 with a ragged last one; rows above / below the slab from the
-    halo messages) against the same rows of the full-grid evaluation."""
+    halo messages) against the same rows of the full-grid evaluation.  precise = 2: the float64-forward instantiation of the halo row
+    pass (spec_ypass_kernel<N, double, true> with the halo rows), which the slab path takes when the viscous amplification exceeds 8."""
     from nns import ops
     B, nx, ny, nl, r0 = 400, 1024, 1024, 44, 100
     d = _rough_fields(1, nx, ny, seed=3)
-    full_fd, full_sp = ops.residual_both(*d, DT, L, L, RHO, NU, precise=False)
-    part = ops.spec_residual_xpass(d[0], d[1], d[2], L, RHO, NU, precise=False)
+    full_fd, full_sp = ops.residual_both(*d, DT, L, L, RHO, NU, precise=precise)
+    part = ops.spec_residual_xpass(d[0], d[1], d[2], L, RHO, NU, precise=precise)
     loc = [t[:, r0:r0 + nl].expand(B, nl, ny).contiguous() for t in d]
     pl = [t[:, r0:r0 + nl].expand(B, nl, ny).contiguous() for t in part]
     top = torch.stack([t[:, r0 - 1].expand(B, ny) for t in d[:3]]).contiguous()
     bot = torch.stack([t[:, r0 + nl].expand(B, ny) for t in d[:3]]).contiguous()
-    hf, hs = ops.residual_both_rowpass_halo(*loc, top, bot, pl, DT, L / nx, L, RHO, NU, precise=False)
+    hf, hs = ops.residual_both_rowpass_halo(*loc, top, bot, pl, DT, L / nx, L, RHO, NU, precise=precise)
     for a, b in zip(hf, full_fd):
         assert bool((a == a[0:1]).all())                                                       # every grid of the batch the same
         assert rel_l2(a[B - 1].cpu().numpy(), b[0, r0:r0 + nl].cpu().numpy()) < 1e-6
@@ -512,3 +516,34 @@ def test_marching_row_pass_chunk_lengths(B, gpu_device):
     for k in range(3):
         same_to_an_ulp(so[k], sp[k])
         assert rel_l2(fo[k].cpu().numpy(), fd[k].cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize('precise', [0, 2])
+def test_column_pass_segments_beyond_32bit_offsets(precise, gpu_device):
+    """The role-split column pass addresses with 32-bit lane offsets inside a grid; a segmented (slab) layout whose source-rank
+    blocks lie >= 2^32 elements apart (the library then takes the kernel with 64-bit row offsets) must give the same numbers as the
+    plain column pass.  Also the float64-forward instantiation of the segmented layout (precise = 2)."""
+    import ctypes
+    from nns import ops, _lib
+    B, nx, ny, seg = 2, 64, 64, 32
+    stride = (1 << 32) + 4096                                 # elements between the two source-rank blocks of one field
+    per = B * seg * ny                                        # one field of one source rank
+    need = stride + 3 * per + 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * need * 4 + (1 << 30):
+        pytest.skip("needs 2 x %.1f GB of device memory" % (need * 4 / 1e9))
+    f = [dev(a) for a in inputs(B, nx)[:3]]
+    ref = ops.spec_residual_xpass(*f, L, RHO, NU, precise=precise)
+    big_in = torch.empty(need, dtype=torch.float32, device='cuda')
+    big_out = torch.empty(need, dtype=torch.float32, device='cuda')
+    for k, t in enumerate(f):                                 # [src][field][grid][seg][ny] with the sources `stride` apart
+        for src in range(nx // seg):
+            big_in[src * stride + k * per: src * stride + (k + 1) * per].view(B, seg, ny).copy_(t[:, src * seg:(src + 1) * seg])
+    q = lambda t, k: ctypes.c_void_p(t.data_ptr() + 4 * k * per)
+    _lib.check(_lib.lib().nns_spec_residual_xpass_seg_f32(q(big_in, 0), q(big_in, 1), q(big_in, 2), q(big_out, 0), q(big_out, 1), q(big_out, 2),
+                                                          B, nx, ny, seg, stride, L, RHO, NU, int(precise), torch.cuda.current_stream().cuda_stream),
+               'nns_spec_residual_xpass_seg_f32')
+    for k in range(3):
+        for src in range(nx // seg):
+            got = big_out[src * stride + k * per: src * stride + (k + 1) * per].view(B, seg, ny)
+            assert torch.equal(got, ref[k][:, src * seg:(src + 1) * seg]), (k, src)

@@ -58,6 +58,11 @@ def _worker(rank, world, port, out):
         res['spec'] = [t.numpy() for t in s.spectral(*loc)]
         both = s.both(*loc)                                     # the fused form: halo under the transposes, one row pass
         res['bfd'], res['bspec'] = [t.numpy() for t in both[0]], [t.numpy() for t in both[1]]
+        # the batch-chunk pipeline (what a stream-ordered transport runs by default): same numbers whatever the chunking
+        both2 = s.both(*loc, chunks=2)
+        spec2 = s.spectral(*loc, chunks=2)
+        for a, b in zip(list(both2[0]) + list(both2[1]) + list(spec2), res['bfd'] + res['bspec'] + res['spec']):
+            np.testing.assert_array_equal(a.numpy(), b)
         np.savez(os.path.join(out, 'r%d.npz' % rank), **{k + '_%d' % i: a for k, v in res.items() for i, a in enumerate(v)})
     finally:
         dist.destroy_process_group()
