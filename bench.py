@@ -481,7 +481,8 @@ def main():
                                      'oracle in cpu_baseline.oracle_check', float64_forward_forced=alt),
                       data='synthetic',
                       config=dict(workload='periodic-box NS residual, %dx%d, batch %d grids per GPU, FD %d-point + Fourier spectral%s'
-                                           % (n, n, B, args.stencil, ' (fused row pass: 2 launches)' if fused else ' (separate launches)'),
+                                           % (n, n, B, args.stencil, ' (fused row pass: 2 launches)' if fused else
+                                              (' (per rank and batch chunk: pack, all-to-all, column pass, all-to-all, unpack, fused row pass)' if slab else ' (separate launches)')),
                                   grid=[n, n], batch_per_gpu=B, global_batch=B if slab else B * world,
                                   parallelism=('row-slab x%d: the same %d grids on all ranks; halo send/recv + 2 all-to-all transposes per evaluation over %s'
                                                % (world, B, 'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)')) if slab

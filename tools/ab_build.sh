@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer helper: build a VARIANT of libnns_hip.so with extra compile flags for same-box A/B timing.
-#   ./ab_build.sh B "-DNNS_TW_LOOKUP=1"   ->  gpurun_ab/libnns_hip_B.so     (use with NNS_LIB_PATH=...)
+#   tools/ab_build.sh B "-DNNS_TW_LOOKUP=1"   ->  ab_variants/libnns_hip_B.so     (use with NNS_LIB_PATH=...)
 set -e
 TAG=$1; FLAGS=$2
 C=neural-navier-stokes_amd/csrc; O=ab_variants; mkdir -p $O/$TAG
