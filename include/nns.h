@@ -238,8 +238,8 @@ int nns_fd_residual_bwd_f64(const double* u, const double* v, const double* g_u,
                             double rho, double nu, int stencil, void* stream);
 /* Vector-Jacobian product of the spectral residual (oracle/periodic.py: spectral_residual_vjp): two fused passes like
  * the forward (columns, then rows), three packed forward (`precise` as for nns_spec_residual_f32) and three inverse (float32)
- * LDS-resident transforms per line -- the conjugate spectral multiplies.  grad_u_prev / grad_v_prev may be null.  nx, ny powers of
- * two in [64, 1024]. */
+ * LDS-resident transforms per line -- the conjugate spectral multiplies.  grad_u_prev / grad_v_prev may be null.  Axis lengths as for
+ * nns_spec_residual_f32: powers of two in [64, 1024] on the FFT engine, any other length 3 .. 2048 as circulant matrices in float64. */
 int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, const float* g_v, const float* g_div,
                               float* grad_u, float* grad_v, float* grad_p, float* grad_u_prev, float* grad_v_prev,
                               int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
@@ -247,7 +247,12 @@ int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, 
 /* Spectral back-end: d/dx <-> i kx, lap <-> -|k|^2 via LDS-resident 1-D FFTs (the operators are
  * separable, so no 2-D transform is materialised): pass 1 transforms columns (axis 0) and leaves
  * the x-part of the residual in r_u, r_v, r_div; pass 2 transforms rows (axis 1) and completes
- * them in place.  nx, ny powers of two in [64, 1024].
+ * them in place.
+ * AXIS LENGTHS.  The FFT engine serves powers of two in [64, 1024] (every BASELINE.json size).  Any other length n in 3 .. 2048 --
+ * the reference drivers' own 51 x 51 and 50 x 50 grids (src/chorin_fd/simulate.py:280-281, src/direct_fd/simulate.py:153-154), 96, 2048 --
+ * takes, per axis, the same operator as a CIRCULANT matrix applied in float64 (csrc/spectral_dense.hip: O(n) multiply-adds per point,
+ * exact to float32 output rounding, `precise` ignored; the first call with a new (n, L) builds the n-vector on the host and copies it,
+ * synchronously).  The two axes of one call choose independently (e.g. 96 x 256).  Longer axes fail with NNS_ERR_UNSUPPORTED.
  * `precise` (every nns_spec_residual_* / nns_residual_both_* entry point) selects the arithmetic of the forward transforms:
  *   0  all-float32: the lines are forward-DIFFERENCED in physical space (exact in float32) and the spectral multiply becomes
  *      a bounded filter, so the white rounding noise of a float32 transform is not amplified by k.  First derivatives come
@@ -267,8 +272,9 @@ int nns_spec_residual_f32(const float* u, const float* v, const float* p, const 
  * whole rows of u, v, p in registers, so the stencil's j-1 / j+1 neighbours are lane rotates.  Rows i-1 / i+1: in the all-float32
  * mode every line of a workgroup marches down a chunk of consecutive rows (row above parked in LDS, row below = the next row's
  * prefetch: no second read); in the float64-forward mode they are re-read from L2 / memory.
- * nx, ny powers of two in [64, 1024] as for nns_spec_residual_f32 (ny = 1024: one row per wave, whole-wave DPP rotates;
- * shorter rows share a wave and use ds_bpermute).  Results equal those of the two separate calls to rounding.
+ * nx, ny powers of two in [64, 1024] run this fused form (ny = 1024: one row per wave, whole-wave DPP rotates; shorter rows share a
+ * wave).  Results equal those of the two separate calls to rounding.  With ny outside the FFT engine's sizes the call IS the two
+ * separate calls (nns_fd_residual_f32 + nns_spec_residual_f32, see its AXIS LENGTHS note); nx alone outside them only swaps the column pass.
  * The six output fields must not overlap the inputs or each other (rows i-1 / i+1 of the inputs are read while other rows'
  * outputs are being written).
  * Measured 11-24 % faster than the two calls at every size (tools/both_sizes_run.py). */

@@ -31,6 +31,11 @@
 namespace nns {
 
 template <typename T> struct C2 { T x, y; };
+// (Round 3, measured and rejected: complex arithmetic on the packed float32 instructions -- a complex multiply is two v_pk_mul/fma_f32 with the
+//  swap and sign folded into op_sel / neg_lo, no moves (checked in the ISA), 22 % fewer vector instructions per line.  But on gfx950 every
+//  v_pk_*_f32 costs a SIMD 4.3-4.5 cycles per wave64 instruction against 2.4 for v_add/v_mul_f32 and 2.7-3.0 for v_fma/v_fmac_f32 with distinct
+//  sources (tools/valu_rate_bench.hip, profiles/r03_valu_rate.txt): two lanes' worth per packed instruction is no faster than two scalar
+//  ones, and the column pass went 0.520 -> 0.555 ms, the fused row pass 0.752 -> 0.768 (profiles/r03_ab_packed_stagger_prio.log).)
 
 template <typename T> __device__ __forceinline__ C2<T> operator+(C2<T> a, C2<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> __device__ __forceinline__ C2<T> operator-(C2<T> a, C2<T> b) { return {a.x - b.x, a.y - b.y}; }

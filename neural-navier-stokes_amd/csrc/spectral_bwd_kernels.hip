@@ -351,19 +351,25 @@ NNS_API int nns_spec_residual_bwd_f32(const float* u, const float* v, const floa
                                       int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu, int precise, void* stream) {
     if (!u || !v || !g_u || !g_v || !g_div || !grad_u || !grad_v || !grad_p || batch < 1)
         return fail(NNS_ERR_INVALID_ARG, "spec_residual_bwd: bad args");
-    if (!pow2_in_range(nx) || !pow2_in_range(ny))
-        return fail(NNS_ERR_UNSUPPORTED, "spec_residual_bwd: nx=%d, ny=%d must be powers of two in [64, 1024]", nx, ny);
     if (Lx == 0 || Ly == 0 || rho == 0 || dt == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_bwd: Lx, Ly, rho, dt must be non-zero");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // per axis: the FFT engine for powers of two in [64, 1024], circulant matrices in float64 for any other length (spectral_dense.hip)
+    if (!spec_len_ok(nx) || !spec_len_ok(ny))
+        return fail(NNS_ERR_UNSUPPORTED, "spec_residual_bwd: nx=%d, ny=%d: powers of two in [64, 1024] (FFT engine) or any length 3 .. %d (dense fallback)", nx, ny, kDenseMaxLen);
+    if (!pow2_in_range(nx)) {
+        if (int rc0 = dense_bwd_xpass(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, batch, nx, ny, Lx, rho, nu, s)) return rc0;
+    }
+    const bool x_done = !pow2_in_range(nx);
     const double kx = 2.0 * M_PI / Lx, ky = 2.0 * M_PI / Ly;
     const AdjK kxp{kx / nx, nu * kx * kx / nx, (float)(1.0 / rho), (float)(1.0 / dt)};
     const AdjK kyp{ky / ny, nu * ky * ky / ny, (float)(1.0 / rho), (float)(1.0 / dt)};
-    int rc = dispatch_n(nx, [&](auto n) {
+    int rc = x_done ? 0 : dispatch_n(nx, [&](auto n) {
         constexpr int N = decltype(n)::value;
         return !spec_f32_mode(precise, nu, nx, Lx) ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s)
                                                   : launch_bwd<N, float>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, nullptr, nullptr, batch, ny, true, kxp, s);
     });
     if (rc) return rc;
+    if (!pow2_in_range(ny)) return dense_bwd_ypass(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, ny, dt, Ly, rho, nu, s);
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
         return !spec_f32_mode(precise, nu, ny, Ly) ? launch_bwd<N, double>(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, grad_u_prev, grad_v_prev, batch, nx, false, kyp, s)

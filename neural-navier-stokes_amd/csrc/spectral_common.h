@@ -138,6 +138,20 @@ inline long spec_grid_cap() {
 
 inline bool pow2_in_range(int n) { return n >= 64 && n <= 1024 && (n & (n - 1)) == 0; }
 
+// spectral_dense.hip: the same operators on an axis of any length 3 .. 2048 as circulant matrices applied in float64 (O(n) per point;
+// what every axis that is not a power of two in [64, 1024] gets).  Same partial-field convention as the FFT passes, so the two
+// directions of one call may use different engines.
+constexpr int kDenseMaxLen = 2048;
+inline bool spec_len_ok(int n) { return pow2_in_range(n) || (n >= 3 && n <= kDenseMaxLen); }
+int dense_xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
+                double Lx, double rho, double nu, hipStream_t s);
+int dense_ypass(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
+                int batch, int nx, int ny, double dt, double Ly, double rho, double nu, hipStream_t s);
+int dense_bwd_xpass(const float* u, const float* v, const float* ga, const float* gb, const float* gd, float* gu, float* gv, float* gp,
+                    int batch, int nx, int ny, double Lx, double rho, double nu, hipStream_t s);
+int dense_bwd_ypass(const float* u, const float* v, const float* ga, const float* gb, const float* gd, float* gu, float* gv, float* gp,
+                    float* gup, float* gvp, int batch, int nx, int ny, double dt, double Ly, double rho, double nu, hipStream_t s);
+
 template <typename F>
 int dispatch_n(int n, F&& f) {
     switch (n) {
@@ -147,7 +161,7 @@ int dispatch_n(int n, F&& f) {
         case 512: return f(std::integral_constant<int, 512>{});
         case 1024: return f(std::integral_constant<int, 1024>{});
     }
-    return fail(NNS_ERR_UNSUPPORTED, "spectral: axis length %d is not a power of two in [64, 1024]", n);
+    return fail(NNS_ERR_UNSUPPORTED, "spectral: axis length %d is not a power of two in [64, 1024] (the FFT engine's sizes)", n);
 }
 
 

@@ -813,6 +813,8 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
         return;
     }
     // ================= transform waves =================
+    // (round 3, rejected by same-box A/B, profiles/r03_ab_packed_stagger_prio.log: waves 4..7 delayed by s_sleep 4 / 8 at every tile start so that
+    //  the two transform waves of a SIMD run out of step: 0.520 -> 0.535 ms; static s_setprio 1 for waves 4..7: 0.520 -> 0.535 ms)
     __syncthreads();                                                            // inputs of the first tile are staged
     for (; t < ntiles; t += gridDim.x) {
         int tx = threadIdx.x;
@@ -957,8 +959,11 @@ int launch_rowmarch(const float* u, const float* v, const float* p, const float*
 int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, float* rd, int batch, int nx, int ny,
           double Lx, double rho, double nu, int precise, hipStream_t s, int seg_rows = 0, long seg_stride = 0) {
     if (!u || !v || !p || !ru || !rv || !rd || batch < 1 || ny < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: bad args");
-    if (!pow2_in_range(nx)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_xpass: nx=%d must be a power of two in [64, 1024]", nx);
     if (Lx == 0 || rho == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_xpass: Lx, rho must be non-zero");
+    if (!pow2_in_range(nx)) {
+        if (seg_rows) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_xpass_seg: nx=%d must be a power of two in [64, 1024] (the segmented layout exists for the FFT engine only)", nx);
+        return dense_xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, s);          // any other length 3 .. 2048: circulant matrices, float64
+    }
     const double ks = 2.0 * M_PI / Lx;
     SpecK k{ks / nx, ks / (rho * nx), nu * ks * ks / nx, 0.f};
     const bool f64 = !spec_f32_mode(precise, nu, nx, Lx);
@@ -982,8 +987,8 @@ int xpass(const float* u, const float* v, const float* p, float* ru, float* rv, 
 int ypass(const float* u, const float* v, const float* p, const float* up, const float* vp, float* ru, float* rv, float* rd,
           int batch, int nx, int ny, double dt, double Ly, double rho, double nu, int precise, hipStream_t s) {
     if (!u || !v || !p || !up || !vp || !ru || !rv || !rd || batch < 1 || nx < 1) return fail(NNS_ERR_INVALID_ARG, "spec_residual_ypass: bad args");
-    if (!pow2_in_range(ny)) return fail(NNS_ERR_UNSUPPORTED, "spec_residual_ypass: ny=%d must be a power of two in [64, 1024]", ny);
     if (Ly == 0 || rho == 0 || dt == 0) return fail(NNS_ERR_INVALID_ARG, "spec_residual_ypass: Ly, rho, dt must be non-zero");
+    if (!pow2_in_range(ny)) return dense_ypass(u, v, p, up, vp, ru, rv, rd, batch, nx, ny, dt, Ly, rho, nu, s);
     const double ks = 2.0 * M_PI / Ly;
     SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const long nrows = (long)batch * nx;
@@ -1003,8 +1008,16 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
         return fail(NNS_ERR_INVALID_ARG, "residual_both: bad args");
     const bool slab = halo_top || halo_bot;               // a row slab: nx is the LOCAL row count (any value >= 3), only ny is transformed here
     if (slab && (!halo_top || !halo_bot || with_xpass)) return fail(NNS_ERR_INVALID_ARG, "residual_both: a row slab needs both halo messages and the row pass only");
-    if (!pow2_in_range(ny) || (!slab && !pow2_in_range(nx))) return fail(NNS_ERR_UNSUPPORTED, "residual_both: nx=%d, ny=%d must be powers of two in [64, 1024]", nx, ny);
     if (Ly == 0 || rho == 0 || dt == 0 || Lx == 0) return fail(NNS_ERR_INVALID_ARG, "residual_both: Lx, Ly, rho, dt must be non-zero");
+    if (!slab && (!spec_len_ok(nx) || !spec_len_ok(ny)))
+        return fail(NNS_ERR_UNSUPPORTED, "residual_both: nx=%d, ny=%d: powers of two in [64, 1024] (FFT engine) or any length 3 .. %d (dense fallback)", nx, ny, kDenseMaxLen);
+    if (!pow2_in_range(ny) && !slab) {
+        // rows the FFT engine does not serve: no fused row pass -- the standalone stencil kernel, then the spectral passes (dense where needed)
+        if (int rc = nns_fd_residual_f32(u, v, p, up, vp, fu, fv, fd, batch, nx, ny, dt, Lx / nx, Ly / ny, rho, nu, 5, s)) return rc;
+        if (with_xpass) { if (int rc = xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, precise, s)) return rc; }
+        return ypass(u, v, p, up, vp, ru, rv, rd, batch, nx, ny, dt, Ly, rho, nu, precise, s);
+    }
+    if (!pow2_in_range(ny)) return fail(NNS_ERR_UNSUPPORTED, "residual_both (row slab): ny=%d must be a power of two in [64, 1024]", ny);
     if (with_xpass) {
         if (int rc = xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, precise, s)) return rc;
     }
@@ -1062,6 +1075,8 @@ NNS_API int nns_spec_residual_ypass_f32(const float* u, const float* v, const fl
 NNS_API int nns_spec_residual_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
                                   float* r_u, float* r_v, float* r_div, int batch, int nx, int ny, double dt, double Lx, double Ly,
                                   double rho, double nu, int precise, void* stream) {
+    if (!spec_len_ok(nx) || !spec_len_ok(ny))                  // before the first launch: both axes must have an engine
+        return fail(NNS_ERR_UNSUPPORTED, "spec_residual: nx=%d, ny=%d: powers of two in [64, 1024] (FFT engine) or any length 3 .. %d (dense fallback)", nx, ny, kDenseMaxLen);
     if (int rc = xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, precise, S(stream))) return rc;
     return ypass(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, Ly, rho, nu, precise, S(stream));
 }

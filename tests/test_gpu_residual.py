@@ -118,13 +118,64 @@ def test_spectral_nyquist_and_single_modes(gpu_device):
 
 
 def test_spectral_unsupported_sizes_raise(gpu_device):
+    """Axis lengths beyond both engines (FFT: powers of two in [64, 1024]; dense circulant fallback: 3 .. 2048) fail loudly, as does the
+    segmented (slab) column pass on a length the FFT engine does not serve."""
     from nns import ops, _lib
-    z = torch.zeros(1, 96, 64, device='cuda')
+    z = torch.zeros(1, 4, 4100, device='cuda')
+    with pytest.raises(_lib.NnsError, match='2048'):
+        ops.spec_residual(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
+    z = torch.zeros(1, 4100, 8, device='cuda')
+    with pytest.raises(_lib.NnsError, match='2048'):
+        ops.spec_residual(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
+    with pytest.raises(_lib.NnsError, match='2048'):
+        ops.spec_residual_bwd(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
+    buf = torch.zeros(2, 3, 1, 48, 8, device='cuda')
     with pytest.raises(_lib.NnsError, match='power of two'):
-        ops.spec_residual(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
-    z = torch.zeros(1, 64, 2048, device='cuda')
-    with pytest.raises(_lib.NnsError):
-        ops.spec_residual(z, z, z, z, z, 1e-3, L, L, 1.0, 0.1)
+        ops.spec_residual_xpass_seg(buf, buf.clone(), 1, 96, 8, 48, L, 1.0, 0.1)
+
+
+@pytest.mark.parametrize('shape', [(2, 51, 51), (1, 50, 50), (2, 96, 96), (1, 96, 256), (1, 128, 100), (3, 7, 9), (1, 3, 64)])
+def test_spectral_residual_any_axis_length(shape, gpu_device):
+    """Axis lengths the FFT engine does not serve (the reference drivers' own 51 x 51 / 50 x 50 grids, src/chorin_fd/simulate.py:280-281,
+    src/direct_fd/simulate.py:153-154; 96; odd and tiny sizes) go through the circulant-matrix form (csrc/spectral_dense.hip), per axis --
+    a power-of-two axis next to an odd one keeps its FFT pass.  Forward, the fused-call surface and the backward against the float64
+    oracle on rough fields, box lengths unequal."""
+    from nns import ops
+    from oracle import periodic as OP
+    rng = np.random.default_rng(sum(shape))
+    B, nx, ny = shape
+    x = np.arange(nx)[:, None] / nx
+    y = np.arange(ny)[None, :] / ny
+    mk = lambda: (np.sin(2 * np.pi * (x + rng.uniform())) * np.cos(2 * np.pi * (y + rng.uniform())) + 0.3 * rng.standard_normal((B, nx, ny))).astype(np.float32)
+    f = [mk() for _ in range(5)]
+    Lx, Ly, dt, rho, nu = 1.5, 4.0, 2e-3, 1.2, 0.01
+    d = [dev(a) for a in f]
+    f64 = [a.astype(np.float64) for a in f]
+    ref = OP.spectral_residual(*f64, dt, Lx, Ly, rho, nu)
+    for g, r in zip(host(ops.spec_residual(*d, dt, Lx, Ly, rho, nu)), ref):
+        assert rel_l2(g, r) <= 1e-6
+    fo, so = ops.residual_both(*d, dt, Lx, Ly, rho, nu)                        # same call surface as the power-of-two sizes
+    ref_fd = OP.fd_residual(*f64, dt, Lx / nx, Ly / ny, rho, nu, 5)
+    for g, r in zip(host(so), ref):
+        assert rel_l2(g, r) <= 1e-6
+    for g, r in zip(host(fo), ref_fd):
+        assert rel_l2(g, r) <= TOL
+    g3 = [mk() for _ in range(3)]
+    got = ops.spec_residual_bwd(d[0], d[1], *[dev(a) for a in g3], dt, Lx, Ly, rho, nu)
+    refb = OP.spectral_residual_vjp(f64[0], f64[1], *[a.astype(np.float64) for a in g3], dt, Lx, Ly, rho, nu)
+    for g, r in zip(host(got), refb):
+        assert rel_l2(g, r) <= 1e-6
+
+
+def test_spectral_residual_2048_dense(gpu_device):
+    """2048 x 2048: beyond the FFT engine's 1024, inside the dense fallback's range (slow -- O(n) per point -- but exact)."""
+    from nns import ops
+    from oracle import periodic as OP
+    f = inputs(1, 2048)
+    got = host(ops.spec_residual(*[dev(a) for a in f], DT, L, L, RHO, NU))
+    ref = OP.spectral_residual(*[a.astype(np.float64) for a in f], DT, L, L, RHO, NU)
+    for g, r in zip(got, ref):
+        assert rel_l2(g, r) <= 1e-6
 
 
 def test_split_passes_equal_fused_call(gpu_device):

@@ -26,6 +26,14 @@ __global__ void rate(double* out, int iters, double seed) {
                 if (KIND == 7) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
                 if (KIND == 8) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[i]) : "v"(c));
                 if (KIND == 9) asm volatile("v_mov_b32 %0, %1" : "=v"(n[i]) : "v"(n[(i + 1) & 15]));
+                // round 3: the forms a complex multiply can be made of
+                if (KIND == 10) asm volatile("v_mul_f32_e32 %0, %0, %1" : "+v"(f[i]) : "v"(cf));
+                if (KIND == 11) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(f[i]) : "v"(cf), "v"(f[(i + 1) & 15]));
+                if (KIND == 12) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(c));
+                if (KIND == 13) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(c));
+                if (KIND == 14) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[i]) : "v"(cf), "v"(f[(i + 1) & 15]));
+                if (KIND == 15) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(d[i]) : "v"(c), "v"(d[(i + 1) & 15]));
+                if (KIND == 16) asm volatile("v_sub_f32_e32 %0, %0, %1" : "+v"(f[i]) : "v"(f[(i + 1) & 15]));
             }
         }
     }
@@ -38,7 +46,7 @@ __global__ void rate(double* out, int iters, double seed) {
 template <int KIND>
 void run(const char* name, double* out) {
     const int iters = 20000;
-    for (int wps : {1, 2, 4}) {           // waves per SIMD: block = 256 * wps threads, one block per CU
+    for (int wps : {1, 2, 3, 4}) {           // waves per SIMD: block = 256 * wps threads, one block per CU
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         hipLaunchKernelGGL(rate<KIND>, dim3(256), dim3(256 * wps), 0, 0, out, 100, 1.0);
         CK(hipEventRecord(e0));
@@ -56,5 +64,7 @@ int main() {
     run<0>("v_add_f64", out); run<1>("v_mul_f64", out); run<2>("v_fma_f64", out);
     run<3>("v_fma_f32", out); run<4>("v_add_f32", out); run<5>("v_add_u32", out);
     run<6>("v_cvt_f32_f64", out); run<7>("v_cvt_f64_f32", out); run<8>("v_pk_fma_f32", out); run<9>("v_mov_b32", out);
+    run<10>("v_mul_f32_e32", out); run<11>("v_fmac_f32_e32", out); run<12>("v_pk_mul_f32", out); run<13>("v_pk_add_f32", out);
+    run<14>("v_fma_f32 3src", out); run<15>("v_pk_fma opsel", out); run<16>("v_sub_f32 2vgpr", out);
     return 0;
 }
