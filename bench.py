@@ -267,15 +267,19 @@ def main():
                     help="N > 1 only.  slab (default): the SAME --batch grids are slab-decomposed by rows over the ranks -- halo "
                          "send/recv for the stencil, 2 all-to-alls per spectral evaluation (strong scaling); "
                          "batch: every rank owns --batch whole grids, no data-path collective (weak scaling)")
-    ap.add_argument('--chunks', type=int, default=None, help='slab mode: batch chunks pipelined through the stages (default: 4 on RCCL, 1 on gloo)')
+    ap.add_argument('--chunks', type=int, default=None, help='slab mode: batch chunks pipelined through the stages (default: 2 on RCCL, 1 on gloo)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` object (BASELINE configs 1, 2, 3, 5; ~20 s, N = 1 only)')
-    ap.add_argument('--launch-timeout', type=float, default=900.0, help='self-launcher: seconds before the child ranks are killed')
+    ap.add_argument('--loopback', action='store_true', help='rehearsal on ONE GPU: --gpus 1 --mode slab --loopback runs the slab path with every message going '
+                    'through a world-1 RCCL process group to the rank itself (device buffers, async collectives; not a scaling number)')
+    ap.add_argument('--launch-timeout', type=float, default=420.0, help='self-launcher: seconds before the child ranks are killed')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))                            # nothing has touched the GPU yet: `import torch` only
     if args.mode is None:
         args.mode = 'slab'
+    if args.loopback and (args.gpus != 1 or args.backend != 'nccl'):
+        raise SystemExit('--loopback is the one-GPU RCCL rehearsal: --gpus 1 --backend nccl')
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -294,9 +298,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.loopback:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.loopback:
+            os.environ.setdefault('MASTER_PORT', str(_free_port())); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)      # "nccl" is RCCL on ROCm
         else:
@@ -310,14 +316,14 @@ def main():
     if rank == 0:
         log('bench: device', _lib.device_info(), 'world', world)
         log('bench: generating %d distinct %dx%d grids on the host ...' % (min(args.distinct, B), n, n))
-    slab = args.mode == 'slab' and world > 1
+    slab = args.mode == 'slab' and (world > 1 or args.loopback)
     f = make_inputs(B, n, args.distinct, 1234 + (0 if slab else 1000 * rank), device)
     eng = ResidualEngine(n, n, dt, rho, nu, L, L, backend='spectral', precise=prec)
     if slab:
         from nns.slab import SlabResidual
         nloc = n // world
         f = [t[:, rank * nloc:(rank + 1) * nloc].contiguous() for t in f]          # this rank's rows of every grid
-        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=prec, chunks=args.chunks)
+        sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=prec, chunks=args.chunks, loopback=args.loopback)
 
         def step():           # per batch chunk: halo exchange under the two transposes + column pass, then ONE fused row pass (5-point stencil)
             sl.both(*f, stencil=args.stencil)
@@ -350,7 +356,7 @@ def main():
     # N > 1 extras, measured after the timed region: what RCCL really saw, one un-pipelined evaluation phase by phase, and the
     # embarrassingly parallel alternative (every rank its own --batch grids)
     multi = None
-    if world > 1:
+    if world > 1 or args.loopback:
         ones = torch.ones(1, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(ones)
         multi = dict(transport=dict(backend=dist.get_backend(), library='RCCL (torch "nccl" on ROCm)' if args.backend == 'nccl' else
@@ -358,6 +364,15 @@ def main():
                                     device_buffers=args.backend == 'nccl'),
                      rccl_ranks=int(ones.item()) if args.backend == 'nccl' else 0, ranks_confirmed_by_all_reduce=int(ones.item()))
         if slab:
+            # how long the HOST takes to enqueue one step (the per-chunk pipeline is ~10 launches / collectives per chunk from Python): if this
+            # exceeds the device time of a step, the step is host-bound
+            torch.cuda.synchronize()
+            th0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            host_ms = 1e3 * (time.perf_counter() - th0) / 10
+            torch.cuda.synchronize()
+            multi['host_enqueue_ms_per_step'] = host_ms
             ph = slab_phases(sl, f, max(3, min(args.steps, 10)))
             keys = sorted(ph)
             t = torch.tensor([ph[k] for k in keys], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
@@ -365,6 +380,19 @@ def main():
             multi['phases'] = dict(ms_max_over_ranks=dict(zip(keys, [float(x) for x in t.tolist()])), ms_rank0=ph,
                                    note='ONE un-pipelined evaluation (chunks=1) with a device synchronisation after every phase; the timed step '
                                         'pipelines %d batch chunks, so its time is less than the sum' % sl._nchunks(B))
+            # the timed path's own numbers against the single-process kernels: rank 0 evaluates grid 0 .. 1 whole (it generated the full
+            # inputs) and compares its rows of them with what the slab-decomposed, chunk-pipelined step just produced -- bitwise expected
+            fd_s, sp_s = sl.both(*f, stencil=args.stencil)
+            torch.cuda.synchronize()
+            if rank == 0:
+                full = make_inputs(min(B, 2), n, args.distinct, 1234, device)
+                fd_1, sp_1 = eng.both(*full, stencil=args.stencil)
+                nl = n // world
+                diffs = [float((a[:full[0].shape[0]] - b[:, :nl]).abs().max()) for a, b in zip(list(fd_s) + list(sp_s), list(fd_1) + list(sp_1))]
+                multi['slab_check'] = dict(compared='rank 0 rows of grids 0..%d: slab-decomposed step vs the single-process kernels on the whole grids' % (full[0].shape[0] - 1),
+                                           max_abs_diff=max(diffs), bitwise_equal=all(x == 0.0 for x in diffs))
+                del full, fd_1, sp_1
+            del fd_s, sp_s
             a2a_bytes = 3.0 * B * (n // world) * n * 4 * (world - 1) / world       # bytes leaving this GPU per all-to-all
             multi['comm'] = dict(all_to_all_bytes_leaving_each_gpu=a2a_bytes, all_to_alls_per_step=2, halo_bytes_sent_each_gpu=2 * 3.0 * B * n * 4,
                                  chunks=sl._nchunks(B),
@@ -475,6 +503,8 @@ def main():
                                   'tests hold the kernels to 1e-5 rel-L2 of that float64 oracle',
                       value=value, unit='residual-updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='strong' if slab else 'weak', vs_baseline=None,
+                      scaling_note=('the SAME %d grids on all %d GPUs: every evaluation moves 24 B/pt across xGMI (u, v, p out, three partials back) '
+                                    'against the 80 B/pt its kernels move in HBM, so the links bound it; `batch_sharded` is the no-collective alternative' % (B, world)) if slab else None,
                       dtype='f32' if prec < 2 else 'f32 fields; f64 forward FFT + f32 inverse FFT; f32 stencil',
                       precision=dict(precise=prec, note='precise=1: the library takes all-float32 transforms on forward-differenced lines while the viscous '
                                      'amplification nu pi N/(sqrt(3) L) <= 8 (1.86 here), float64 forward transforms otherwise; rel-L2 against the float64 '

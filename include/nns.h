@@ -291,11 +291,14 @@ int nns_residual_both_rowpass_f32(const float* u, const float* v, const float* p
 /* The row pass on a ROW SLAB [batch][nx_local][ny] of grids sharded by rows over ranks (nns/slab.py):
  * the stencil's row above local row 0 / below local row nx_local-1 is read from halo_top / halo_bot, two
  * [3 (u, v, p)][batch][ny] messages holding the neighbour ranks' edge rows; dx is the grid spacing along x (the slab does not
- * know the global row count); nx_local >= 3, any value.  Same arithmetic per point as nns_residual_both_rowpass_f32. */
+ * know the global row count); nx_local >= 3, any value.  Same arithmetic per point as nns_residual_both_rowpass_f32.
+ * halo_field_stride: elements between the u, v and p blocks of a halo message; 0 = batch * ny (a message made for exactly these grids).
+ * A larger value lets a call on a CHUNK of the batch read its rows out of a message exchanged once for the whole batch
+ * (halo_top + first_grid * ny, stride = whole_batch * ny): nns/slab.py pipelines batch chunks and sends one halo message per step. */
 int nns_residual_both_rowpass_halo_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
                                        const float* halo_top, const float* halo_bot,
                                        float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
-                                       int batch, int nx_local, int ny, double dt, double dx, double Ly, double rho, double nu,
+                                       int batch, int nx_local, int ny, long halo_field_stride, double dt, double dx, double Ly, double rho, double nu,
                                        int precise, void* stream);
 /* The two halves of nns_spec_residual_f32, exposed for slab-decomposed (multi-GPU) use:
  * x-pass on a column slab [nx, ny_local] (needs complete columns), y-pass on a row slab

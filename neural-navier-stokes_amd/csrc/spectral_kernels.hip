@@ -1003,7 +1003,7 @@ int ypass(const float* u, const float* v, const float* p, const float* up, const
 // FD 5-point + spectral residual of the same inputs: spectral x-pass, then the row pass with the stencil fused in.
 int residual_both(const float* u, const float* v, const float* p, const float* up, const float* vp, float* fu, float* fv, float* fd,
                   float* ru, float* rv, float* rd, int batch, int nx, int ny, double dt, double Lx, double Ly, double rho, double nu,
-                  int precise, hipStream_t s, bool with_xpass, const float* halo_top = nullptr, const float* halo_bot = nullptr) {
+                  int precise, hipStream_t s, bool with_xpass, const float* halo_top = nullptr, const float* halo_bot = nullptr, long halo_fstride = 0) {
     if (!u || !v || !p || !up || !vp || !fu || !fv || !fd || !ru || !rv || !rd || batch < 1 || nx < 3)
         return fail(NNS_ERR_INVALID_ARG, "residual_both: bad args");
     const bool slab = halo_top || halo_bot;               // a row slab: nx is the LOCAL row count (any value >= 3), only ny is transformed here
@@ -1025,7 +1025,7 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     const SpecK k{ks / ny, ks / (rho * ny), nu * ks * ks / ny, (float)(1.0 / dt)};
     const FdK fk{(float)(1.0 / (2 * dx)), (float)(1.0 / (2 * dy)), (float)(1.0 / rho), (float)nu, 1.0 / (dx * dx), 1.0 / (dy * dy),
                  (float)(1.0 / (dx * dx)), (float)(1.0 / (dy * dy))};
-    const HaloK hk{halo_top, halo_bot, (long)batch * ny};
+    const HaloK hk{halo_top, halo_bot, halo_fstride > 0 ? halo_fstride : (long)batch * ny};
     return dispatch_n(ny, [&](auto n) {
         constexpr int N = decltype(n)::value;
         const long nrows = (long)batch * nx;
@@ -1053,10 +1053,13 @@ NNS_API int nns_residual_both_rowpass_f32(const float* u, const float* v, const 
 NNS_API int nns_residual_both_rowpass_halo_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
                                                const float* halo_top, const float* halo_bot,
                                                float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
-                                               int batch, int nx_local, int ny, double dt, double dx, double Ly, double rho, double nu, int precise, void* stream) {
+                                               int batch, int nx_local, int ny, long halo_field_stride, double dt, double dx, double Ly, double rho, double nu,
+                                               int precise, void* stream) {
     if (!halo_top || !halo_bot) return fail(NNS_ERR_INVALID_ARG, "residual_both_rowpass_halo: halo_top and halo_bot are required");
+    if (halo_field_stride != 0 && halo_field_stride < (long)batch * ny)
+        return fail(NNS_ERR_INVALID_ARG, "residual_both_rowpass_halo: halo_field_stride=%ld must be 0 (= batch * ny) or >= batch * ny = %ld", halo_field_stride, (long)batch * ny);
     return residual_both(u, v, p, u_prev, v_prev, fd_r_u, fd_r_v, fd_r_div, sp_r_u, sp_r_v, sp_r_div, batch, nx_local, ny, dt, dx, Ly, rho, nu, precise,
-                         S(stream), false, halo_top, halo_bot);
+                         S(stream), false, halo_top, halo_bot, halo_field_stride);
 }
 NNS_API int nns_spec_residual_xpass_f32(const float* u, const float* v, const float* p, float* r_u, float* r_v, float* r_div,
                                         int batch, int nx, int ny, double Lx, double rho, double nu, int precise, void* stream) {

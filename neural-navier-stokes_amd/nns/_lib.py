@@ -62,7 +62,7 @@ _SINGLE = {
     'nns_spec_residual_bwd_f32': [_P] * 10 + [_I] * 3 + [_D] * 5 + [_I, _P],
     'nns_spec_residual_xpass_f32': [_P] * 6 + [_I] * 3 + [_D] * 3 + [_I, _P],
     'nns_spec_residual_xpass_seg_f32': [_P] * 6 + [_I] * 4 + [_L] + [_D] * 3 + [_I, _P],
-    'nns_residual_both_rowpass_halo_f32': [_P] * 13 + [_I] * 3 + [_D] * 5 + [_I, _P],
+    'nns_residual_both_rowpass_halo_f32': [_P] * 13 + [_I] * 3 + [_L] + [_D] * 5 + [_I, _P],
     'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_spec_derivs_f32': [_P] * 4 + [_I] * 3 + [_D, _D, _I, _P],
     'nns_spec_rfft2_f32': [_P, _P, _I, _I, _I, _P],

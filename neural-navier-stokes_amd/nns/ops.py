@@ -323,19 +323,23 @@ def spec_residual_xpass_seg(recv, send, B, nx, nyl, seg_rows, Lx, rho, nu, preci
     return send
 
 
-def residual_both_rowpass_halo(u, v, p, u_prev, v_prev, halo_top, halo_bot, sp_partials, dt, dx, Ly, rho, nu, precise=True, out_fd=None):
+def residual_both_rowpass_halo(u, v, p, u_prev, v_prev, halo_top, halo_bot, sp_partials, dt, dx, Ly, rho, nu, precise=True, out_fd=None, halo_grid0=0):
     """The fused row pass on a row slab (nns_residual_both_rowpass_halo_f32): sp_partials holds the column pass's partials on
-    entry and the spectral residual on return; returns ((fd r_u, r_v, r_div), sp_partials)."""
+    entry and the spectral residual on return; returns ((fd r_u, r_v, r_div), sp_partials).  halo_top / halo_bot: [3, Bh, ny] messages;
+    Bh may exceed this call's batch B -- the call then covers grids halo_grid0 .. halo_grid0 + B - 1 of the batch the messages were
+    exchanged for (nns/slab.py: one halo exchange per step, batch chunks pipelined)."""
     suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev, *sp_partials)
     if suf != '_f32':
         raise TypeError("residual_both_rowpass_halo: float32 fields")
+    Bh = halo_top.shape[1] if halo_top.dim() == 3 else -1
     for h in (halo_top, halo_bot):
-        if not (h.is_cuda and h.is_contiguous() and h.dtype == u.dtype and tuple(h.shape) == (3, B, ny)):
-            raise ValueError("residual_both_rowpass_halo: halo messages must be contiguous [3, %d, %d] float32 device tensors" % (B, ny))
+        if not (h.is_cuda and h.is_contiguous() and h.dtype == u.dtype and tuple(h.shape) == (3, Bh, ny) and 0 <= halo_grid0 and halo_grid0 + B <= Bh):
+            raise ValueError("residual_both_rowpass_halo: halo messages must be contiguous [3, >= %d, %d] float32 device tensors" % (halo_grid0 + B, ny))
     fo = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
     so = sp_partials
-    check(_lib.lib().nns_residual_both_rowpass_halo_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(halo_top), _p(halo_bot),
-                                                        _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny,
+    off = halo_grid0 * ny * 4
+    check(_lib.lib().nns_residual_both_rowpass_halo_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(halo_top) + off, _p(halo_bot) + off,
+                                                        _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny, Bh * ny,
                                                         dt, dx, Ly, rho, nu, _prec(precise), _stream()), 'nns_residual_both_rowpass_halo_f32')
     return fo, so
 

@@ -63,15 +63,16 @@ class HipCompute(object):
         from . import ops
         return ops.spec_residual_ypass_(u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise)
 
-    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None):
+    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None, halo_grid0=0):
         from . import ops
-        return ops.residual_both_rowpass_halo(u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=out_fd)
+        return ops.residual_both_rowpass_halo(u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=out_fd, halo_grid0=halo_grid0)
 
 
 class SlabResidual(object):
     def __init__(self, nx, ny, dt, rho, nu, Lx=2 * math.pi, Ly=2 * math.pi, group=None, compute=None, precise=True, chunks=None, loopback=None):
-        """chunks: how many batch chunks `both` / `spectral` pipeline through their stages (None: 4 on a stream-ordered transport
-        with more than one rank, 1 otherwise -- see `_pipeline`)."""
+        """chunks: how many batch chunks `both` / `spectral` pipeline through their stages (None: 2 on a stream-ordered transport
+        with more than one rank, 1 otherwise -- see `_pipeline`; every chunk costs the host ~0.1 ms of Python to enqueue, so more
+        chunks than the device time of a step can hide make the step host-bound)."""
         self.tr = Transport(group, loopback=loopback)
         self.chunks = chunks
         self.group, self.P, self.rank = group, self.tr.P, self.tr.rank
@@ -125,7 +126,7 @@ class SlabResidual(object):
         c = chunks if chunks is not None else self.chunks
         if c is None:
             # a stream-ordered transport overlaps chunk c+1's transfers with chunk c's kernels; a staged (blocking) one gains nothing
-            c = 4 if (self.tr.backend == 'nccl' and not self.tr.local) else 1
+            c = 2 if (self.tr.backend == 'nccl' and not self.tr.local) else 1
         return max(1, min(int(c), B))
 
     def _pipeline(self, u, v, p, finish, chunks=None):
@@ -188,22 +189,25 @@ class SlabResidual(object):
         return tuple(self._pipeline(u, v, p, fin, chunks))
 
     def both(self, u, v, p, u_prev, v_prev, stencil=5, chunks=None):
-        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- per batch chunk the halo exchange
-        travels under the transposes and the column pass, then ONE row pass does the stencil and finishes the spectral residual;
-        the chunks are pipelined (`_pipeline`)."""
+        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- the halo exchange travels under the
+        transposes and the column pass of the first batch chunk, then ONE row pass per chunk does the stencil and finishes the spectral
+        residual; the chunks are pipelined (`_pipeline`)."""
         if stencil != 5 or u.dtype not in getattr(self.compute, 'fused_dtypes', (torch.float32,)):
             return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev, chunks)
         B = u.shape[0]
         C = self._nchunks(B, chunks)
-        # the halo messages of every chunk leave first: tiny, and the row pass of chunk c needs them two ticks later
-        halos = [self.start_halo([t[B * c // C:B * (c + 1) // C] for t in (u, v, p)], tag=c) for c in range(C)]
+        # ONE halo exchange for the whole batch leaves first (two pack launches, one grouped send/recv): tiny, and the first row pass needs it
+        # two ticks later; every chunk's row pass reads its grids out of the same two messages (halo_grid0)
+        h, top, bot = self.start_halo([u, v, p])
         out_fd = tuple(torch.empty_like(u) for _ in range(3))
+        waited = []
 
         def fin(c, sl, parts):
-            h, top, bot = halos[c]
-            h.wait()
+            if not waited:
+                h.wait()
+                waited.append(True)
             self.compute.both_rowpass_halo(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], top, bot, parts, self.dt, self.dx, self.Ly, self.rho, self.nu,
-                                           self.precise, out_fd=tuple(t[sl] for t in out_fd))
+                                           self.precise, out_fd=tuple(t[sl] for t in out_fd), halo_grid0=sl.start)
         parts = self._pipeline(u, v, p, fin, C)
         return out_fd, tuple(parts)
 

@@ -66,7 +66,8 @@ expect('spec_residual nx=5000', L.nns_spec_residual_f32(P, P, P, P, P, P, P, P, 
 expect('spec_residual_bwd ny=2', L.nns_spec_residual_bwd_f32(*([P] * 10), 1, 64, 2, 1e-3, 6.28, 6.28, 1.0, 0.01, 1, None), UNSUPPORTED)
 expect('residual_both ny=4096', L.nns_residual_both_f32(*([P] * 11), 1, 64, 4096, 1e-3, 6.28, 6.28, 1.0, 0.01, 1, None), UNSUPPORTED)
 expect('residual_both dt=0', L.nns_residual_both_f32(*([P] * 11), 1, 64, 64, 0.0, 6.28, 6.28, 1.0, 0.01, 1, None), INVALID)
-expect('rowpass_halo without halos', L.nns_residual_both_rowpass_halo_f32(P, P, P, P, P, None, None, P, P, P, P, P, P, 1, 8, 64, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('rowpass_halo without halos', L.nns_residual_both_rowpass_halo_f32(P, P, P, P, P, None, None, P, P, P, P, P, P, 1, 8, 64, 0, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('rowpass_halo short halo stride', L.nns_residual_both_rowpass_halo_f32(*([P] * 13), 2, 8, 64, 64, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), INVALID)
 expect('xpass_seg seg_rows=3', L.nns_spec_residual_xpass_seg_f32(P, P, P, P, P, P, 1, 64, 8, 3, 1000, 6.28, 1.0, 0.01, 1, None), INVALID)
 expect('xpass_seg short stride', L.nns_spec_residual_xpass_seg_f32(P, P, P, P, P, P, 1, 64, 8, 16, 4, 6.28, 1.0, 0.01, 1, None), INVALID)
 expect('fd_residual stencil=7', L.nns_fd_residual_f32(P, P, P, P, P, P, P, P, 1, 8, 8, 1e-3, 0.1, 0.1, 1.0, 0.01, 7, None), INVALID)

@@ -65,8 +65,10 @@ class OracleCompute(OracleLines):
             o.copy_(_t(a))
         return ru, rv, rd
 
-    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None):
+    def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None, halo_grid0=0):
         fd = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
+        g = slice(halo_grid0, halo_grid0 + u.shape[0])               # this call's grids of the whole-batch halo messages
+        top, bot = top[:, g], bot[:, g]
         self.fd_residual_halo(u, v, p, up, vp, top, bot, dt, dx, Ly / u.shape[2], rho, nu, 5, None, fd)
         return fd, self.spec_ypass(u, v, p, up, vp, *partials, dt, Ly, rho, nu, precise)
 
