@@ -101,3 +101,48 @@ def test_physics_informed_training_step(gpu_device):
     opt = torch.optim.Adam(model.parameters(), lr=2e-3)
     hist = [train_step(model, eng, opt, state, target, lam=0.1)[0].item() for _ in range(40)]
     assert hist[-1] < 0.6 * hist[0], hist[::8]
+
+
+def test_physics_informed_spectral_loss_on_reference_driver_grids(gpu_device):
+    """The reference's drivers produce 51 x 51 fields (src/chorin_fd/simulate.py:280-281; 50 x 50 in src/direct_fd/simulate.py:153-154):
+    the spectral physics loss must take them as they come.  Frames of the chorin_fd mirror's own cavity run go through
+    ResidualEngine(backend='spectral') -- circulant-matrix form on both axes (csrc/spectral_dense.hip) -- forward and autograd backward
+    against the float64 oracle, and the field stepper trains on them."""
+    import numpy as np
+    import torch
+    from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+    from nns.chorin_fd import NavierStokesSystem
+    from nns.neural_spectral.physics_informed import FieldStepper, train_step
+    from nns.periodic import ResidualEngine
+    from oracle import periodic as OP
+    from conftest import rel_l2
+    n, dt, nu, rho, Lbox = 51, 1e-3, 0.1, 1.0, 2.0
+    dx = dy = 2. / (n - 1)
+    u_bc = [D(0., 'left', dx, dy), D(1., 'right', dx, dy), D(0., 'top', dx, dy), D(0., 'bottom', dx, dy)]
+    v_bc = [D(0., 'left', dx, dy), D(0., 'right', dx, dy), D(0., 'top', dx, dy), D(0., 'bottom', dx, dy)]
+    p_bc = [D(0., 'top', dx, dy), N(0., 'bottom', dx, dy), N(0., 'left', dx, dy), N(0., 'right', dx, dy)]
+    z = np.zeros((n, n))
+    us, vs, ps = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=6, nit=50, nx=n, ny=n, dt=dt, rho=rho, nu=nu, beta=1.25,
+                                    method='explicit').simulate()
+    assert us.shape == (6, n, n) and np.abs(us[-1]).max() > 1e-3
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    u, v, p, up, vp = f32(us[1:]), f32(vs[1:]), f32(ps[1:]), f32(us[:-1]), f32(vs[:-1])          # 5 consecutive frame pairs
+    eng = ResidualEngine(n, n, dt, rho, nu, Lbox, Lbox, backend='spectral')
+    d = [torch.as_tensor(a, device='cuda').requires_grad_(True) for a in (u, v, p, up, vp)]
+    r = eng.differentiable(*d)
+    ref = OP.spectral_residual(*[a.astype(np.float64) for a in (u, v, p, up, vp)], dt, Lbox, Lbox, rho, nu)
+    for g, w in zip(r, ref):
+        assert rel_l2(g.detach().cpu().numpy(), w) <= 1e-6
+    g3 = [torch.randn_like(t) for t in r]
+    torch.autograd.backward(r, g3)
+    refb = OP.spectral_residual_vjp(u.astype(np.float64), v.astype(np.float64), *[t.cpu().numpy().astype(np.float64) for t in g3], dt, Lbox, Lbox, rho, nu)
+    for t, w in zip(d, refb):
+        assert rel_l2(t.grad.cpu().numpy(), w) <= 1e-6
+    # and the physics-informed step trains on these frames
+    state = torch.as_tensor(np.stack([up, vp, p], axis=1), device='cuda')
+    target = torch.as_tensor(np.stack([u, v, p], axis=1), device='cuda')
+    torch.manual_seed(1)
+    model = FieldStepper(depth=4, width=32).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    hist = [train_step(model, eng, opt, state, target, lam=1e-6)[0].item() for _ in range(30)]
+    assert np.isfinite(hist).all() and hist[-1] < hist[0], hist[::6]

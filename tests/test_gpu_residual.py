@@ -447,8 +447,14 @@ def test_fused_both_residuals(nx, ny, batch, gpu_device):
     for a, b in zip(e_sp, s_sp):
         same_to_an_ulp(a, b)
     assert all(rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6 for a, b in zip(e_fd, s_fd))
-    with pytest.raises(RuntimeError):
-        ops.residual_both(*[t[:, :, :48].contiguous() for t in d], DT, Lx, Ly, RHO, NU)        # not a power of two: loud, no silent fallback
+    # a row length the FFT engine does not serve: the same call IS the two separate calls (stencil kernel + spectral passes, dense along y)
+    d48 = [t[:, :, :48].contiguous() for t in d]
+    f48, s48 = ops.residual_both(*d48, DT, Lx, Ly, RHO, NU)
+    for a, b in zip(list(f48) + list(s48), list(ops.fd_residual(*d48, DT, Lx / nx, Ly / 48, RHO, NU, 5)) + list(ops.spec_residual(*d48, DT, Lx, Ly, RHO, NU))):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):                                          # beyond both engines: loud
+        z = torch.zeros(1, 8, 4100, device='cuda')
+        ops.residual_both(z, z, z, z, z, DT, Lx, Ly, RHO, NU)
 
 
 @pytest.mark.parametrize('nx,ny', [(64, 52), (128, 20), (1024, 12), (256, 8)])
