@@ -930,6 +930,8 @@ inline int device_cus() {
 // batch size, so grid b of a large batch equals the same grid evaluated alone bit for bit.
 template <int N>
 int march_chunk_rows(long nrows, int nx) {
+    static const int forced = [] { const char* e = getenv("NNS_MARCH_R"); return e ? atoi(e) : 0; }();      // tuning override (a power of two)
+    if (forced > 0) return forced > nx ? nx : forced;
     const long tl = (long)device_cus() * SpecLds<N, float>::LINES;
     const long r = nrows / tl;
     int R = 1;

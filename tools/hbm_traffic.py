@@ -12,9 +12,11 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
             kn = r['Kernel_Name']
             s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass', 'spec_rowmarch') if n in kn), None)          # spec_xpass also matches spec_xpass_split_kernel
             if s == 'spec_ypass' and re.search(r'spec_ypass_kernel<[^>]*true>', kn):
-                s = 'both_rowpass'                              # spec_ypass_kernel<N, TF, FUSE_FD = true>
+                s = 'both_rowpass_f64_forward'                  # spec_ypass_kernel<N, TF, FUSE_FD = true>: the fused row pass of the float64-forward mode
             if s == 'spec_rowmarch':
-                s = 'both_rowpass'                              # the marching form of the fused row pass
+                s = 'both_rowpass'                              # the marching form of the fused row pass (the headline's)
+            if s == 'spec_xpass' and 'double' in kn:
+                s = 'spec_xpass_f64_forward' 
             if s and r['Counter_Name'] == c:
                 acc[s].append(float(r['Counter_Value']))
     val[c] = {k: sum(v) / len(v) for k, v in acc.items()}

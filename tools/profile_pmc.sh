@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
-  timeout -k 5 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$name.log; return 1; }
+  timeout -k 5 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $R/gpurun_out/pmc_$name.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$name.log; return 1; }
   echo "pass $name done"
 }
 run wait SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
