@@ -177,6 +177,33 @@ def test_pixel_mlp_basisfunc_vs_golden_and_deep_bf16(gpu_device):
         PixelMLP(9, 16).cuda()(torch.randn(1, 3, 4, 4, device='cuda'))           # > 8 layers: unsupported, loud
 
 
+def test_pixel_mlp_config3_full_shape_properties(gpu_device):
+    """BASELINE config 3's field-prediction MLP (depth 8, width 64, bf16 operands) at the shape the bench times it on -- 16 x 512^2 pixels --
+    through size-independent properties: run-to-run determinism (bitwise), batch independence (item b of the batch == the item alone,
+    bitwise), pixel independence (a permuted copy of 4096 pixels gives the permuted outputs, bitwise), and a 4096-pixel sample against the
+    float64 oracle at bf16 tolerance (float32 operands: 1e-5)."""
+    from nns.neural_spectral.spectral_ode import PixelMLP
+    from oracle import neural as ON
+    torch.manual_seed(11)
+    m = PixelMLP(8, 64).cuda()
+    for b in m.biases:
+        torch.nn.init.normal_(b, std=0.3)
+    x = torch.randn(16, 3, 512, 512, device='cuda')
+    y = m(x, bf16=True)
+    assert y.shape == x.shape and bool(torch.isfinite(y).all())
+    assert torch.equal(y, m(x, bf16=True))                                            # deterministic
+    for b in (0, 7, 15):
+        assert torch.equal(y[b:b + 1], m(x[b:b + 1].contiguous(), bf16=True))          # batch independent
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    idx = torch.randint(0, 512 * 512, (4096,), device='cuda', generator=g)
+    xs = x[5].reshape(3, -1)[:, idx].reshape(1, 3, 64, 64).contiguous()              # 4096 pixels of item 5, as a 64 x 64 field
+    ys = m(xs, bf16=True)
+    assert torch.equal(ys.reshape(3, -1), y[5].reshape(3, -1)[:, idx])               # per-pixel operator: position does not matter
+    ref = ON.pixel_mlp([w.detach().cpu().double() for w in m.weights], [b.detach().cpu().double() for b in m.biases], xs.cpu().double()).numpy()
+    assert rel_l2(ys.cpu().numpy(), ref) < 5e-2
+    assert rel_l2(m(xs, bf16=False).cpu().numpy(), ref) < 1e-5
+
+
 def test_pixel_mlp_backward_exact_integers(gpu_device):
     """Indexing check of the fused backward with data on which bf16 arithmetic is EXACT: sparse weights in {-1, 0, 1},
     integer inputs and upstream gradients, so every operand and every partial sum is a small integer.  Any wrong lane /
