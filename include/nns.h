@@ -258,7 +258,11 @@ int nns_spec_residual_bwd_f32(const float* u, const float* v, const float* g_u, 
  *      a bounded filter, so the white rounding noise of a float32 transform is not amplified by k.  First derivatives come
  *      out at float32 accuracy for any input; the viscous term keeps a relative amplification of rms nu pi N / (sqrt(3) L)
  *      per axis (1.9 at 1024^2, nu = 2 pi / 1000: 1.1e-6 rel-L2 against the float64 oracle; <= 4e-6 measured for nu <= 1);
- *   1  the library picks, per pass: all-float32 while that factor is <= 8, otherwise as 2;
+ *   1  the library picks: all-float32 while that factor is <= 8, otherwise as 2.  Entry points that evaluate BOTH directions
+ *      (nns_spec_residual_f32, nns_residual_both_f32, nns_spec_residual_bwd_f32) decide once from the larger of the two axes' factors, so
+ *      an anisotropic grid never mixes arithmetic; the single-direction entry points (xpass / ypass / rowpass) decide from their own
+ *      axis -- callers that combine them (nns/slab.py) resolve the policy themselves and pass 0 or 2.
+ *      (API note: until round 1 `precise = 1` meant float64 forward transforms unconditionally; that is `precise = 2` now.)
  *   2  forward transforms and spectral multiply in float64, inverse in float32 (2-4e-7 rel-L2), whatever the viscosity.
  * nns_spec_residual_bwd_f32 follows the same rule (its three packed pairs per line are differenced the same way);
  * nns_spec_derivs_f32: 0 = plain all-float32, non-zero = float64 forward. */
@@ -347,7 +351,9 @@ int nns_ode_mlp_bwd_f32(const float* z0, const float* W0, const float* b0, const
 /* The time-parallel form of that backward (anode/adjoint.py:38-70 walks the steps backwards one by one; every step's Jacobian
  * depends only on its own stored input state, so all of them can be formed at once):
  *   nns_ode_mlp_bwd_steps_f32  backward of `rows` INDEPENDENT single steps y -> y' of size dt: grad_y[r] = (dy'/dy)^T grad_out[r],
- *                              parameter gradients summed over the rows (work: nns_ode_mlp_bwd_workspace(rows) bytes);
+ *                              parameter gradients summed over the rows (work: nns_ode_mlp_bwd_workspace(rows) bytes); the six
+ *                              parameter-gradient pointers may ALL be NULL (pass 1 below wants grad_y only: their products, the
+ *                              zero-fills and the atomics are then skipped);
  *   nns_ode_adjoint_chain_f32  lam[Nt-1] = g[Nt-1], lam[s-1] = g[s-1] + lam[s] J[s]: the adjoint recurrence on the K x K step
  *                              Jacobians J [Nt][mb][K][K] (K <= 64), g, lam [Nt][mb][K].
  * Pass 1: rows (s, b, i) with grad_out = e_i give J; chain; pass 2: rows (s, b) with grad_out = lam[s][b] give the parameter

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
                                                          float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
                                                          float* __restrict__ gb2, float* __restrict__ work,
                                                          int mb, int K, int Nt, int method, float dt_in) {
+    const bool want_pg = gW1 != nullptr;                 // uniform: the Jacobian pass of the time-parallel adjoint wants grad_y only (nns_ode_mlp_bwd_steps_f32 with NULL gW* / gb*)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
@@ -338,9 +339,11 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             for (int e = tid; e < TB * HS; e += NT) { BA[e] = w[TB * KS + e]; BB[e] = w[TB * KS + TB * HS + e]; }      // h1, h2
             __syncthreads();
             // layer 3 backward: gWt2[k][n] += h2^T GF ; gb2 += colsum GF ; gh2 = GF W2 -> gz2 = gh2 * elu'(z2)
+            if (want_pg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) { const int tile = wave + 4 * t, it = tile / 2, nt = tile % 2; aW2[t] = mma_atb(BB, HS, 16 * it, GF, KS, 16 * nt, aW2[t], lane); }
             if (tid < KP) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += GF[b * KS + tid]; ab2 += sacc; }
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int k0 = 16 * (wave * 2 + t);
@@ -352,9 +355,11 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             }
             __syncthreads();
             // layer 2 backward: gWt1 += h1^T gz2 ; gb1 += colsum gz2 ; gh1 = gz2 W1 -> gz1 = gh1 * relu'(z1)   (into BB)
+            if (want_pg) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) { const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8; aW1[t] = mma_atb(BA, HS, 16 * it, BC, HS, 16 * nt, aW1[t], lane); }
             if (tid < H) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += BC[b * HS + tid]; ab1 += sacc; }
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int k0 = 16 * (wave * 2 + t);
@@ -366,9 +371,11 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             }
             __syncthreads();
             // layer 1 backward: gWt0 += S^T gz1 ; gb0 += colsum gz1 ; GS = gz1 W0
+            if (want_pg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) { const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8; aW0[t] = mma_atb(S, KS, 16 * it, BB, HS, 16 * nt, aW0[t], lane); }
             if (tid < H) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += BB[b * HS + tid]; ab0 += sacc; }
+            }
             if (wave < KP / 16) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = mma_abt(BB, HS, m.Wt0, HS, 16 * wave, H, acc, lane);      // GS[b][k] = sum_n gz1[b][n] Wt0[k][n]
@@ -397,6 +404,7 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
         const int b = e / KS, k = e % KS;
         if (row0 + b < mb && k < K) gz0[(size_t)(row0 + b) * K + k] = A[e];
     }
+    if (!want_pg) return;
     const int c = lane & 15, r0 = 4 * (lane >> 4);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {                          // gW1[n][k] = gWt1[k][n]
@@ -1116,9 +1124,10 @@ static int ode_mlp_bwd_impl(const char* what, const float* z0, const float* W0, 
                             const float* b2, const float* states, const float* grad_out, float* grad_z0, float* gW0, float* gb0,
                             float* gW1, float* gb1, float* gW2, float* gb2, void* work, int mb, int K, int hidden, int Nt, int method, float dt_in,
                             void* stream) {
-    if (!z0 || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !states || !grad_out || !grad_z0 || !gW0 || !gb0 || !gW1 || !gb1 || !gW2 || !gb2 || !work ||
+    const bool all_pg = gW0 && gb0 && gW1 && gb1 && gW2 && gb2, no_pg = !gW0 && !gb0 && !gW1 && !gb1 && !gW2 && !gb2;
+    if (!z0 || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !states || !grad_out || !grad_z0 || !(all_pg || (no_pg && dt_in > 0.f)) || !work ||
         mb < 1 || Nt < 1)
-        return fail(NNS_ERR_INVALID_ARG, "%s: bad args", what);
+        return fail(NNS_ERR_INVALID_ARG, "%s: bad args (the six parameter-gradient pointers: all set, or -- independent steps only -- all NULL)", what);
     if (hidden != H) return fail(NNS_ERR_UNSUPPORTED, "%s: hidden width %d (fixed at %d)", what, hidden, H);
     if (K < 1 || K > KP) return fail(NNS_ERR_UNSUPPORTED, "%s: K=%d not in [1, %d]", what, K, KP);
     if (method_id(method) < 0) return fail(NNS_ERR_INVALID_ARG, "%s: method %d", what, method);
@@ -1130,12 +1139,15 @@ static int ode_mlp_bwd_impl(const char* what, const float* z0, const float* W0, 
     }
     hipStream_t s = S(stream);
     // the parameter gradients are accumulated with atomics: zero them first (stream-ordered memset nodes)
-    hipError_t e = hipMemsetAsync(gW0, 0, (size_t)H * K * sizeof(float), s);
+    hipError_t e = hipSuccess;
+    if (all_pg) {
+    e = hipMemsetAsync(gW0, 0, (size_t)H * K * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gb0, 0, H * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gW1, 0, (size_t)H * H * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gb1, 0, H * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gW2, 0, (size_t)K * H * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(gb2, 0, K * sizeof(float), s);
+    }
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
     hipLaunchKernelGGL(ode_mlp_bwd_kernel, dim3((mb + TB - 1) / TB), dim3(NT), kBwdLds, s, z0, W0, b0, W1, b1, W2, b2, states, grad_out,
                        grad_z0, gW0, gb0, gW1, gb1, gW2, gb2, reinterpret_cast<float*>(work), mb, K, Nt, method, dt_in);

@@ -356,6 +356,7 @@ NNS_API int nns_spec_residual_bwd_f32(const float* u, const float* v, const floa
     // per axis: the FFT engine for powers of two in [64, 1024], circulant matrices in float64 for any other length (spectral_dense.hip)
     if (!spec_len_ok(nx) || !spec_len_ok(ny))
         return fail(NNS_ERR_UNSUPPORTED, "spec_residual_bwd: nx=%d, ny=%d: powers of two in [64, 1024] (FFT engine) or any length 3 .. %d (dense fallback)", nx, ny, kDenseMaxLen);
+    precise = spec_resolve_precise(precise, nu, nx, Lx, ny, Ly);                    // one arithmetic for both passes
     if (!pow2_in_range(nx)) {
         if (int rc0 = dense_bwd_xpass(u, v, g_u, g_v, g_div, grad_u, grad_v, grad_p, batch, nx, ny, Lx, rho, nu, s)) return rc0;
     }

@@ -121,12 +121,22 @@ __device__ __forceinline__ float right_of(const float (&x)[16], int tid) {
 // (1.9 at the headline configuration: 1.1e-6 rel-L2 against the float64 oracle, 4e-6 worst case over nu <= 1 on resolved fields;
 // tools/spec_accuracy_f32.py, profiles/r02_accuracy_f32diff.json).  precise = 1 takes it while that factor is <= 8 and the float64
 // forward transform otherwise; precise = 0 always, precise >= 2 never (NNS_SPEC_F64=1 in the environment: as precise = 2).
+inline bool pow2_in_range(int n) { return n >= 64 && n <= 1024 && (n & (n - 1)) == 0; }
 constexpr double kF32AmpMax = 8.0;
 inline bool spec_f32_mode(int precise, double nu, int n, double len) {
     if (!precise) return true;
     static const bool force64 = [] { const char* e = getenv("NNS_SPEC_F64"); return e && atoi(e) != 0; }();
     if (precise >= 2 || force64) return false;
     return std::fabs(nu) * M_PI * n / (1.7320508075688772 * std::fabs(len)) <= kF32AmpMax;
+}
+
+// A WHOLE evaluation (both directions) decides once: all-float32 only if BOTH transformed axes allow it -- an anisotropic grid must not run
+// its two passes in different arithmetic.  Returns the `precise` value to hand to the per-axis passes: 0 or 2.  (Axes served by the
+// dense circulant path do not take part: they are float64 throughout.)
+inline int spec_resolve_precise(int precise, double nu, int nx, double Lx, int ny, double Ly) {
+    const bool fx = !pow2_in_range(nx) || spec_f32_mode(precise, nu, nx, Lx);
+    const bool fy = !pow2_in_range(ny) || spec_f32_mode(precise, nu, ny, Ly);
+    return fx && fy ? 0 : 2;
 }
 
 // workgroups per launch (grid-stride over tiles): 2 generations per CU -- each generation pays the twiddle-table
@@ -136,7 +146,6 @@ inline long spec_grid_cap() {
     return cap;
 }
 
-inline bool pow2_in_range(int n) { return n >= 64 && n <= 1024 && (n & (n - 1)) == 0; }
 
 // spectral_dense.hip: the same operators on an axis of any length 3 .. 2048 as circulant matrices applied in float64 (O(n) per point;
 // what every axis that is not a power of two in [64, 1024] gets).  Same partial-field convention as the FFT passes, so the two

@@ -1011,6 +1011,7 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     const bool slab = halo_top || halo_bot;               // a row slab: nx is the LOCAL row count (any value >= 3), only ny is transformed here
     if (slab && (!halo_top || !halo_bot || with_xpass)) return fail(NNS_ERR_INVALID_ARG, "residual_both: a row slab needs both halo messages and the row pass only");
     if (Ly == 0 || rho == 0 || dt == 0 || Lx == 0) return fail(NNS_ERR_INVALID_ARG, "residual_both: Lx, Ly, rho, dt must be non-zero");
+    if (with_xpass) precise = spec_resolve_precise(precise, nu, nx, Lx, ny, Ly);       // a whole evaluation: one arithmetic for both passes
     if (!slab && (!spec_len_ok(nx) || !spec_len_ok(ny)))
         return fail(NNS_ERR_UNSUPPORTED, "residual_both: nx=%d, ny=%d: powers of two in [64, 1024] (FFT engine) or any length 3 .. %d (dense fallback)", nx, ny, kDenseMaxLen);
     if (!pow2_in_range(ny) && !slab) {
@@ -1082,6 +1083,7 @@ NNS_API int nns_spec_residual_f32(const float* u, const float* v, const float* p
                                   double rho, double nu, int precise, void* stream) {
     if (!spec_len_ok(nx) || !spec_len_ok(ny))                  // before the first launch: both axes must have an engine
         return fail(NNS_ERR_UNSUPPORTED, "spec_residual: nx=%d, ny=%d: powers of two in [64, 1024] (FFT engine) or any length 3 .. %d (dense fallback)", nx, ny, kDenseMaxLen);
-    if (int rc = xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, precise, S(stream))) return rc;
-    return ypass(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, Ly, rho, nu, precise, S(stream));
+    const int pr = spec_resolve_precise(precise, nu, nx, Lx, ny, Ly);       // one arithmetic for both passes
+    if (int rc = xpass(u, v, p, r_u, r_v, r_div, batch, nx, ny, Lx, rho, nu, pr, S(stream))) return rc;
+    return ypass(u, v, p, u_prev, v_prev, r_u, r_v, r_div, batch, nx, ny, dt, Ly, rho, nu, pr, S(stream));
 }

@@ -17,9 +17,17 @@ import torch
 from .. import ops
 
 _METHODS = ('Euler', 'RK2', 'RK4')
-# the time-parallel adjoint is used while its Nt * mb * K single-step rows fill the chip about twice over (16 rows per workgroup,
-# 256 CUs); beyond that the sequential kernel, whose cost does not grow with K, does less work
-_PARALLEL_ROWS = 2 * 256 * 16
+_parallel_rows = None
+
+
+def _parallel_row_limit():
+    """The time-parallel adjoint is used while its Nt * mb * K single-step rows fill the chip about twice over (16 rows per workgroup, one
+    workgroup per CU); beyond that the sequential kernel, whose cost does not grow with K, does less work."""
+    global _parallel_rows
+    if _parallel_rows is None:
+        from .. import _lib
+        _parallel_rows = 2 * _lib.device_info()['cu_count'] * 16
+    return _parallel_rows
 
 
 class _OdeMlpFn(torch.autograd.Function):
@@ -38,7 +46,7 @@ class _OdeMlpFn(torch.autograd.Function):
         Nt, method = ctx.Nt, ctx.method
         mb, K = z0.shape
         grad_out = grad_out.contiguous()
-        if Nt > 1 and mb * Nt * K <= _PARALLEL_ROWS:
+        if Nt > 1 and mb * Nt * K <= _parallel_row_limit():
             # TIME-PARALLEL adjoint.  The checkpointing adjoint (anode/adjoint.py:52-70) walks the Nt steps backwards one after the
             # other -- one workgroup's worth of work per 16 rows, Nt dependent steps deep (66 us each on one CU).  But the
             # Jacobian of step s depends only on its stored input state y_s, so: (1) all Nt * mb step Jacobians at once, as the
@@ -49,7 +57,7 @@ class _OdeMlpFn(torch.autograd.Function):
             ys = torch.cat([z0[None], out[:-1]])                                              # y_s, the input state of step s: [Nt, mb, K]
             rows = ys[:, :, None, :].expand(Nt, mb, K, K).reshape(Nt * mb * K, K).contiguous()
             eye = torch.eye(K, dtype=z0.dtype, device=z0.device).repeat(Nt * mb, 1)
-            J, _ = ops.ode_mlp_bwd_steps(rows, *p, eye, 1. / Nt, method)                      # J[s, b, i, :] = (dy_{s+1} / dy_s)^T e_i
+            J, _ = ops.ode_mlp_bwd_steps(rows, *p, eye, 1. / Nt, method, want_param_grads=False)   # J[s, b, i, :] = (dy_{s+1} / dy_s)^T e_i
             lam = ops.ode_adjoint_chain(J.view(Nt, mb, K, K), grad_out)
             gy, gs = ops.ode_mlp_bwd_steps(ys.reshape(Nt * mb, K).contiguous(), *p, lam.reshape(Nt * mb, K), 1. / Nt, method)
             return (gy.view(Nt, mb, K)[0].contiguous(), *gs, None, None)

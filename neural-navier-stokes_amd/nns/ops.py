@@ -442,16 +442,17 @@ def ode_mlp_bwd(z0, W0, b0, W1, b1, W2, b2, states, grad_out, Nt, method):
     return gz0, gs
 
 
-def ode_mlp_bwd_steps(y, W0, b0, W1, b1, W2, b2, grad_out, dt, method):
+def ode_mlp_bwd_steps(y, W0, b0, W1, b1, W2, b2, grad_out, dt, method, want_param_grads=True):
     """Backward of rows INDEPENDENT single steps of size dt (nns_ode_mlp_bwd_steps_f32): returns (grad_y [rows, K], parameter
-    gradients summed over the rows)."""
+    gradients summed over the rows -- None with want_param_grads=False: the kernel then skips their products, memsets and atomics)."""
     _f32(y, W0, b0, W1, b1, W2, b2, grad_out)
     rows, K = y.shape
     gy = torch.empty_like(y)
-    gs = [torch.empty_like(t) for t in (W0, b0, W1, b1, W2, b2)]
+    gs = [torch.empty_like(t) for t in (W0, b0, W1, b1, W2, b2)] if want_param_grads else None
     work = torch.empty(_lib.lib().nns_ode_mlp_bwd_workspace(rows) // 4, dtype=torch.float32, device=y.device)
     check(_lib.lib().nns_ode_mlp_bwd_steps_f32(_p(y), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2), _p(grad_out), _p(gy),
-                                               *[_p(g) for g in gs], _p(work), rows, K, W1.shape[0], float(dt), ODE_METHODS[method], _stream()),
+                                               *([_p(g) for g in gs] if want_param_grads else [None] * 6), _p(work), rows, K, W1.shape[0], float(dt),
+                                               ODE_METHODS[method], _stream()),
           'nns_ode_mlp_bwd_steps_f32')
     return gy, gs
 

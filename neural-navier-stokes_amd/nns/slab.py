@@ -84,6 +84,11 @@ class SlabResidual(object):
         self.dt, self.rho, self.nu, self.Lx, self.Ly = dt, rho, nu, Lx, Ly
         self.dx, self.dy = Lx / nx, Ly / ny
         self.compute = compute if compute is not None else HipCompute()
+        # the library's automatic pick (precise = True / 1) is made per pass; a sharded evaluation calls the passes one by one, so the
+        # decision is taken HERE, once, from both axes (all-float32 transforms only while nu pi N / (sqrt(3) L) <= 8 on both)
+        if precise is True or (precise is not False and int(precise) == 1):
+            amp = max(abs(nu) * math.pi * n / (math.sqrt(3.) * abs(l)) for n, l in ((nx, Lx), (ny, Ly)))
+            precise = 0 if amp <= 8.0 else 2
         self.precise = precise
         self._bufs = {}
 

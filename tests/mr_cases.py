@@ -28,6 +28,11 @@ def rank_residual(rank, world):
     bf, bs = s.both(*loc)
     for i in range(3):
         res['bfd_%d' % i], res['bspec_%d' % i] = bf[i].cpu().numpy(), bs[i].cpu().numpy()
+    # the float64-forward arithmetic of the same paths (segmented column pass and halo row pass with TF = double)
+    s2 = SlabResidual(N, N, DT, RHO, NU, L, L, precise=2)
+    b2f, b2s = s2.both(*loc)
+    for i in range(3):
+        res['b2fd_%d' % i], res['b2spec_%d' % i] = b2f[i].cpu().numpy(), b2s[i].cpu().numpy()
     # back-to-back calls reuse the message buffers; the batch-chunk pipeline (the default on RCCL) must not change a bit
     for chunks in (1, 2, 2):
         bf2, bs2 = s.both(*loc, chunks=chunks)

@@ -65,11 +65,13 @@ def _check_slab_residual(parts):
     single = {'fd5': ops.fd_residual(*d, MC.DT, h, h, MC.RHO, MC.NU, 5), 'fd9': ops.fd_residual(*d, MC.DT, h, h, MC.RHO, MC.NU, 9),
               'spec': ops.spec_residual(*d, MC.DT, MC.L, MC.L, MC.RHO, MC.NU)}
     single['bfd'], single['bspec'] = ops.residual_both(*d, MC.DT, MC.L, MC.L, MC.RHO, MC.NU)
+    single['b2fd'], single['b2spec'] = ops.residual_both(*d, MC.DT, MC.L, MC.L, MC.RHO, MC.NU, precise=2)
     f64 = [a.astype(np.float64) for a in f]
     oracle = {'fd5': OP.fd_residual(*f64, MC.DT, h, h, MC.RHO, MC.NU, 5), 'fd9': OP.fd_residual(*f64, MC.DT, h, h, MC.RHO, MC.NU, 9),
               'spec': OP.spectral_residual(*f64, MC.DT, MC.L, MC.L, MC.RHO, MC.NU)}
     oracle['bfd'], oracle['bspec'] = oracle['fd5'], oracle['spec']
-    for key in ('fd5', 'fd9', 'spec', 'bfd', 'bspec'):
+    oracle['b2fd'], oracle['b2spec'] = oracle['fd5'], oracle['spec']
+    for key in ('fd5', 'fd9', 'spec', 'bfd', 'bspec', 'b2fd', 'b2spec'):
         got = cat(key)
         for i in range(3):
             assert got[i].shape == (MC.B, MC.N, MC.N)
