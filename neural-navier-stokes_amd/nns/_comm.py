@@ -44,7 +44,8 @@ class Transport(object):
         # loopback: with ONE rank, still send every message through the process group (to this rank itself) instead of the local copy
         if loopback is None:
             loopback = os.environ.get('NNS_COMM_LOOPBACK', '0') == '1'
-        self.loopback = bool(loopback) and self.P == 1 and dist.is_initialized()
+        # (RCCL only: it carries a rank's messages to itself; gloo has no self-send -- a world-1 gloo group stays on local copies)
+        self.loopback = bool(loopback) and self.P == 1 and dist.is_initialized() and self.backend == 'nccl'
 
     @property
     def local(self):

@@ -245,3 +245,26 @@ def test_slab_chorin_fd_semi_implicit_column_slabs(world, tmp_path):
     for name, ref in (('u', ur), ('v', vr), ('p', pr)):
         got = np.concatenate([d[name] for d in parts], axis=2)
         assert got.shape == ref.shape and np.array_equal(got, ref), name
+
+
+def _loopback_worker(rank, world, port, out):
+    """loopback=True is the one-GPU rehearsal of the RCCL transport (a rank's messages go through the process group to itself,
+    tests/test_gpu_multirank.py); gloo has no self-send, so on a world-1 gloo group the request degrades to the local copies."""
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nns.slab import SlabResidual
+        f = fields()
+        loc = [torch.from_numpy(np.ascontiguousarray(a)) for a in f]
+        s = SlabResidual(NX, NY, DT, RHO, NU, LX, LY, compute=OracleCompute(), loopback=True)
+        assert not s.tr.loopback and s.tr.local
+        ref = OP.spectral_residual(*f, DT, LX, LY, RHO, NU)
+        for chunks in (1, 2):
+            for x, y in zip(s.both(*loc, chunks=chunks)[1], ref):
+                np.testing.assert_allclose(x.numpy(), y, rtol=1e-10, atol=1e-10)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_one_loopback_request_on_gloo_stays_local(tmp_path):
+    mp.spawn(_loopback_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
