@@ -14,31 +14,12 @@
 //             c(i) = (i&3) + 8*(i>>2): the two rows register i holds in lane halves 0 / 1)
 //   bfloat16: v_mfma_f32_32x32x16_bf16 (k-step s uses registers 8s..8s+7 packed pairwise to bf16; element j of
 //             lane half h is channel 16s + 8*(j>>2) + 4h + (j&3))
-#include "nns_common.h"
+#include "pixel_mlp_common.h"
 
 using namespace nns;
+using namespace nns::pm;
 
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) short;      // 8 bf16 in 4 VGPRs
-
-constexpr int kMaxLayers = 8;
-constexpr int kMaxWidth = 64;
-
-struct PixelMlpDesc {
-    int nlayers;
-    int cin[kMaxLayers], cout[kMaxLayers];
-    int woff[kMaxLayers], boff[kMaxLayers];      // offsets (floats) into the packed weight / bias arrays
-    int lds_off[kMaxLayers];                     // offset (bytes) of the layer's pre-permuted fragments in LDS
-    int lds_bias[kMaxLayers];                    // offset (bytes) of the layer's padded bias
-};
-
-__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }     // C/D map, 32x32
-
-__device__ __forceinline__ unsigned short f2bf(float x) {          // round-to-nearest-even; NaN-safe via the plain cast
-    return __builtin_bit_cast(unsigned short, (__bf16)x);
-}
 
 // LDS image of a layer's weights, one entry per (out tile ot, k block, lane):
 //   float32 : [ot][kb = in/32][i = 0..15][lane 64]  float   = W[32 ot + (lane&31)][32 kb + c(i) + 4 (lane>>5)]
@@ -74,8 +55,11 @@ __device__ void stage_weights(const PixelMlpDesc& d, const float* __restrict__ W
 // Forward launch geometry: kFwdThreads / 64 waves share one LDS copy of the weights.  With 50-60 KB of fragments
 // (depth 8, width 64, bf16) two workgroups fit a CU, so 6 waves per workgroup give 3 waves per SIMD (<= 170 VGPRs)
 // instead of 2; the next tile's input pixels are loaded while the current tile runs through the layers.
+// Round 3, same-box A/B at depth 8 / width 64 / 16 x 512^2 (profiles/r03_ab_pixel_mlp_fwd.log): 256 threads 0.374 ms, 384 threads 0.43 ms, 512 threads
+// 0.355 ms (one staging of the weights per eight waves); requesting the weight fragments 2 or 4 ahead instead of 1: no change (0.372 / 0.376) --
+// the fragment latency is not what keeps the matrix pipe at 34 % busy.
 #ifndef NNS_PM_THREADS
-#define NNS_PM_THREADS 256
+#define NNS_PM_THREADS 512
 #endif
 constexpr int kFwdThreads = NNS_PM_THREADS, kFwdWaves = kFwdThreads / 64;
 
@@ -119,9 +103,7 @@ __global__ __launch_bounds__(kGenThreads) void pixel_mlp_fwd_kernel(const float*
             // instead of ~150 (the kernel was VALU-bound: 1600 VALU per tile for 54 MFMAs).
             bf16x8 fr[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) fr[s][j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
+            for (int s = 0; s < 4; ++s) fr[s] = pack8<false>(act[s >> 1], 8 * (s & 1));
             const int nl = d.nlayers;
             for (int l = 0; l < nl; ++l) {
                 const int cin = d.cin[l], cout = d.cout[l];
@@ -142,14 +124,8 @@ __global__ __launch_bounds__(kGenThreads) void pixel_mlp_fwd_kernel(const float*
                     }
                 }
                 if (l + 1 < nl) {
-                    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        bf16x8 t;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(act[s >> 1][8 * (s & 1) + j]);
-                        fr[s] = __builtin_elementwise_max(t, zero);
-                    }
+                    for (int s = 0; s < 4; ++s) fr[s] = pack8<true>(act[s >> 1], 8 * (s & 1));
                 }
             }
         } else {
@@ -204,96 +180,6 @@ __global__ __launch_bounds__(kGenThreads) void pixel_mlp_fwd_kernel(const float*
 // `s_waitcnt lgkmcnt(0)` in front of every MFMA: 12 % MFMA utilisation.)  Padding costs 64 instead of 54 MFMAs per
 // tile at depth 8 / width 64 / 3 in / 3 out.
 // LDS image: [layer][ot][s][lane 64][8] bf16 fragments, then [layer][32 OT] float biases.
-template <int OT>
-struct UniLds {
-    static constexpr int SS = 2 * OT;
-    static constexpr int W_BYTES = OT * SS * 64 * 16;            // fragments of one layer
-    static constexpr int B_BYTES = OT * 32 * 4;
-    __host__ __device__ static int total(int nlayers) { return nlayers * (W_BYTES + B_BYTES); }
-};
-
-// Staging walks the REAL [out][in] matrices with consecutive threads on consecutive input channels (coalesced reads, no
-// div/mod per element) and scatters into the zero-filled fragment image.  (Walking the image and gathering from global
-// memory instead cost ~100 us per workgroup -- more than the whole tile loop at depth 8 / width 64.)
-template <int OT>
-__device__ void stage_uniform(const PixelMlpDesc& d, const float* __restrict__ W, const float* __restrict__ B, unsigned char* lds, int tid, int nthreads) {
-    using U = UniLds<OT>;
-    constexpr int SS = U::SS;
-    const int total = U::total(d.nlayers);
-    for (int e = tid; e < total / 16; e += nthreads) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    for (int l = 0; l < d.nlayers; ++l) {
-        const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
-        const float* Wl = W + d.woff[l];
-        unsigned short* dst = reinterpret_cast<unsigned short*>(lds + l * U::W_BYTES);
-        int row = tid / cin, k = tid - row * cin;                 // one division per thread and layer, then incremental
-        const int drow = nthreads / cin, dk = nthreads - drow * cin;
-        for (int e = tid; e < n; e += nthreads) {
-            const int ot = row >> 5, r = row & 31, s2 = k >> 4, kk = k & 15;
-            const int lane = r + 32 * ((kk >> 2) & 1), j = 4 * (kk >> 3) + (kk & 3);
-            dst[(((ot * SS + s2) * 64 + lane) << 3) + j] = f2bf(Wl[e]);
-            row += drow; k += dk;
-            if (k >= cin) { k -= cin; ++row; }
-        }
-        float* bl = reinterpret_cast<float*>(lds + d.nlayers * U::W_BYTES + l * U::B_BYTES);
-        for (int e = tid; e < cout; e += nthreads) bl[e] = B[d.boff[l] + e];
-    }
-}
-
-// Tile I/O without per-site branches.  Fragment element (s, j) of lane half h holds channel 16 s + 8 (j>>2) + 4 h + (j&3)
-// and accumulator register i of tile t holds channel 32 t + (i&3) + 8 (i>>2) + 4 h: both increase with the site index,
-// so the sites are visited in channel order and the walk stops (uniformly) at the first site beyond the channel count --
-// 3 channels touch 3 sites, not 64.  Loads are unconditional (pixel and channel clamped into range) and zeroed by a
-// select; stores are masked per lane.
-template <int SS, bool SMALL>
-__device__ __forceinline__ void load_frags(const float* __restrict__ xb, size_t P, int cin0, bool ok, int h, bf16x8 (&f)[SS]) {
-#pragma unroll
-    for (int s = 0; s < SS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[s][j] = 0;
-    if constexpr (SMALL) {      // cin0 <= 4, the usual (u, v, p) input: channels 0..3 sit in elements 0..3 of fragment 0, lane half 0 only
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = xb[(size_t)(j < cin0 ? j : 0) * P];
-            f[0][j] = (short)f2bf((ok && h == 0 && j < cin0) ? v : 0.f);
-        }
-        return;
-    } else {
-#pragma unroll
-    for (int s = 0; s < SS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int cmin = 16 * s + 8 * (j >> 2) + (j & 3);
-            if (cmin >= cin0) return;
-            const int c = cmin + 4 * h;
-            const float v = xb[(size_t)(c < cin0 ? c : cin0 - 1) * P];
-            f[s][j] = (short)f2bf((ok && c < cin0) ? v : 0.f);
-        }
-    }
-}
-
-template <int OT, bool SMALL>
-__device__ __forceinline__ void store_acc(float* __restrict__ yb, size_t P, int cout, int h, const f32x16 (&a)[OT]) {
-    if constexpr (SMALL) {            // channels 0..3 = registers 0..3 of tile 0, lane half 0
-        if (h == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < cout) yb[(size_t)i * P] = a[0][i];
-        }
-        return;
-    } else {
-#pragma unroll
-    for (int t = 0; t < OT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rmin = 32 * t + (i & 3) + 8 * (i >> 2);
-            if (rmin >= cout) return;
-            const int c = rmin + 4 * h;
-            if (c < cout) yb[(size_t)c * P] = a[t][i];
-        }
-    }
-}
-
 // PT = 2 pixel tiles (64 pixels) per wave and pass: every weight fragment read from LDS feeds two MFMAs and the bias
 // is read once for both tiles.  With one tile per pass the kernel is LDS-bandwidth-bound: a 64x64 layer re-reads 8 KB of
 // fragments + 8 KB of bias per 256 MFMA cycles of ONE SIMD, i.e. the CU's whole 128 B/clk, twice over.
@@ -312,6 +198,10 @@ __global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     const long ngroups = (npix_total + 32 * kPT - 1) / (32 * kPT);
     const long gstride = (long)gridDim.x * kFwdWaves;
     const unsigned char* bias0 = lds + nl * U::W_BYTES;
+#ifndef NNS_PM_STAGGER
+#define NNS_PM_STAGGER 0           // s_sleep argument (64-cycle units) for the second half of the workgroup's waves, once, before the tile loop
+#endif
+    if (NNS_PM_STAGGER && wave >= kFwdWaves / 2) __builtin_amdgcn_s_sleep(NNS_PM_STAGGER);
     // input pixels of group g as bf16 operand fragments (zero beyond cin0 / the last pixel)
     auto load_group = [&](long g, bf16x8 (&f)[kPT][SS]) {
 #pragma unroll
@@ -339,33 +229,39 @@ __global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
                 for (int i = 0; i < 16; ++i) bn[ot][i] = bl[32 * ot + acc_row(i, h)];
         };
         fetch_bias(0);
-        bf16x8 w = wl0[0];
+#ifndef NNS_PM_PF
+#define NNS_PM_PF 1                // weight fragments requested ahead of use (1, 2 or 4): the fragments of all layers are one contiguous stream in LDS
+#endif
+        constexpr int NF = OT * SS, PF = (NNS_PM_PF <= NF && NF % NNS_PM_PF == 0) ? NNS_PM_PF : 1;      // the queue is indexed at compile time
+        const int nfr = nl * NF;
+        bf16x8 q[PF];
+#pragma unroll
+        for (int dq = 0; dq < PF; ++dq) q[dq] = wl0[(dq < nfr ? dq : nfr - 1) * 64];
         for (int l = 0; l < nl; ++l) {
-            const bf16x8* wl = wl0 + (size_t)l * (U::W_BYTES / 16);
-            const int ln = l + 1 < nl ? l + 1 : l;
 #pragma unroll
-            for (int idx = 0; idx < OT * SS; ++idx) {
+            for (int idx = 0; idx < NF; ++idx) {
                 const int ot = idx / SS, s2 = idx % SS;
-                const bf16x8 wn = idx + 1 < OT * SS ? wl[(idx + 1) * 64] : wl0[(size_t)ln * (U::W_BYTES / 16)];
+                const bf16x8 w = q[idx % PF];
+                int nn = l * NF + idx + PF;
+                nn = nn < nfr ? nn : nfr - 1;
+                q[idx % PF] = wl0[nn * 64];
+#ifndef NNS_PM_EXP
+#define NNS_PM_EXP 0               // timing probes (wrong results): 1 = no accumulator -> operand conversion between layers, 2 = no MFMAs, 3 = no bias reads
+#endif
 #pragma unroll
-                for (int pt = 0; pt < kPT; ++pt)
-                    acc[pt][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fr[pt][s2], s2 == 0 ? bn[ot] : acc[pt][ot], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one LDS read (fragment n+1) ...
+                for (int pt = 0; pt < kPT; ++pt) {
+                    if (NNS_PM_EXP == 2) { asm volatile("" :: "v"(w), "v"(fr[pt][s2])); if (s2 == 0) acc[pt][ot] = bn[ot]; }
+                    else acc[pt][ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fr[pt][s2], s2 == 0 ? bn[ot] : acc[pt][ot], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one LDS read (fragment n + PF) ...
                 __builtin_amdgcn_sched_group_barrier(0x008, kPT, 0);      // ... ahead of the MFMAs of fragment n
-                w = wn;
             }
-            if (l + 1 < nl) {
-                fetch_bias(l + 1);
-                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (l + 1 < nl && NNS_PM_EXP != 1) {
+                if (NNS_PM_EXP != 3) fetch_bias(l + 1);
 #pragma unroll
                 for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
-                    for (int s = 0; s < SS; ++s) {
-                        bf16x8 t;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(acc[pt][s >> 1][8 * (s & 1) + j]);
-                        fr[pt][s] = __builtin_elementwise_max(t, zero);
-                    }
+                    for (int s = 0; s < SS; ++s) fr[pt][s] = pack8<true>(acc[pt][s >> 1], 8 * (s & 1));
             }
         }
 #pragma unroll
@@ -376,6 +272,9 @@ __global__ __launch_bounds__(kFwdThreads) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
+#ifndef NNS_PM_PIPE
+#define NNS_PM_PIPE 1              // widths 33..64 with <= 4 channels in and out: 1 = pixel_mlp_fwd_pipe4_kernel (pixel_mlp_fwd4.hip), 0 = pixel_mlp_fwd_uniform_kernel<2, true>
+#endif
 template <int OT, bool SMALLIO>
 int launch_fwd_uniform(const float* x, const float* weights, const float* biases, float* y, long npix, int P, const PixelMlpDesc& d, hipStream_t s) {
     const int lds = UniLds<OT>::total(d.nlayers);
@@ -384,7 +283,8 @@ int launch_fwd_uniform(const float* x, const float* weights, const float* biases
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const long ngroups = (npix + 32 * kPT - 1) / (32 * kPT);
     // persistent: one generation of workgroups (2 per CU fit by LDS), so the weights are staged once per workgroup
-    long blocks = (ngroups + kFwdWaves - 1) / kFwdWaves; if (blocks > 512) blocks = 512;
+    const long cap = kFwdThreads > 256 ? 256 : 512;          // workgroups resident at once (8-wave workgroups: one per CU by registers)
+    long blocks = (ngroups + kFwdWaves - 1) / kFwdWaves; if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((pixel_mlp_fwd_uniform_kernel<OT, SMALLIO>), dim3((unsigned)blocks), dim3(kFwdThreads), lds, s, x, weights, biases, y, npix, P, d);
     return check_launch("pixel_mlp_fwd");
 }
@@ -410,9 +310,6 @@ int launch_fwd_uniform(const float* x, const float* weights, const float* biases
 // Per layer and tile: 8 + 8 + 8 (OT = 2) MFMA 32x32x16.  Partial gradients go to per-workgroup (OT = 2) or per-wave
 // (OT = 1) workspace slices; pixel_mlp_reduce_kernel adds the slices in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------------------------
-using bf16x4 = __attribute__((ext_vector_type(4))) short;
-using bf16x2v = __attribute__((ext_vector_type(2))) __bf16;
-
 template <int OT>
 struct BwdLds {
     static constexpr int SS = 2 * OT, CH = 32 * OT;
@@ -560,14 +457,8 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 #pragma unroll
                     for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<ROWB>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
                 }
-                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int s = 0; s < SS; ++s) {
-                    bf16x8 t;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(acc[s >> 1][8 * (s & 1) + j]);
-                    afrag[l + 1][s] = __builtin_elementwise_max(t, zero);
-                }
+                for (int s = 0; s < SS; ++s) afrag[l + 1][s] = pack8<true>(acc[s >> 1], 8 * (s & 1));
             }
         }
         // ---------------- backward
@@ -576,9 +467,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
             f32x16 dl[OT];
             load_acc<OT, SMALLIO>(gy + (size_t)b * coutL * P + p, (size_t)P, coutL, ok, h, dl);
 #pragma unroll
-            for (int s = 0; s < SS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dfrag[s][j] = (short)f2bf(dl[s >> 1][8 * (s & 1) + j]);
+            for (int s = 0; s < SS; ++s) dfrag[s] = pack8<false>(dl[s >> 1], 8 * (s & 1));
         }
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
@@ -632,9 +521,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
                 if (l > 0) {
                     // ReLU mask a_{l-1} != 0 (activations are >= 0), then the next layer's operand fragments
 #pragma unroll
-                    for (int s = 0; s < SS; ++s)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) dfrag[s][j] = afrag[l][s][j] != 0 ? (short)f2bf(nd[s >> 1][8 * (s & 1) + j]) : (short)0;
+                    for (int s = 0; s < SS; ++s) dfrag[s] = pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
                 } else if (ok) {
                     store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
@@ -786,14 +673,8 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #pragma unroll
                     for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<ROWB>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
                 }
-                const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int s = 0; s < SS; ++s) {
-                    bf16x8 t;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t[j] = (short)f2bf(acc[s >> 1][8 * (s & 1) + j]);
-                    afrag[l + 1][s] = __builtin_elementwise_max(t, zero);
-                }
+                for (int s = 0; s < SS; ++s) afrag[l + 1][s] = pack8<true>(acc[s >> 1], 8 * (s & 1));
             }
         }
         // ---------------- backward
@@ -802,9 +683,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
             f32x16 dl[OT];
             load_acc<OT, SMALLIO>(gy + (size_t)b * coutL * P + p, (size_t)P, coutL, ok, h, dl);
 #pragma unroll
-            for (int s = 0; s < SS; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dfrag[s][j] = (short)f2bf(dl[s >> 1][8 * (s & 1) + j]);
+            for (int s = 0; s < SS; ++s) dfrag[s] = pack8<false>(dl[s >> 1], 8 * (s & 1));
         }
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
@@ -836,9 +715,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 __syncthreads();                                                // layer l's images are written: over to the gradient waves
                 if (l > 0) {
 #pragma unroll
-                    for (int s = 0; s < SS; ++s)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) dfrag[s][j] = afrag[l][s][j] != 0 ? (short)f2bf(nd[s >> 1][8 * (s & 1) + j]) : (short)0;
+                    for (int s = 0; s < SS; ++s) dfrag[s] = pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
                 } else if (ok) {
                     store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
@@ -1093,6 +970,7 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
         for (int l = 0; l <= nlayers; ++l) maxw = widths_host[l] > maxw ? widths_host[l] : maxw;
         const bool small = widths_host[0] <= 4 && widths_host[nlayers] <= 4;          // (u, v, p)-sized input and output: straight-line tile I/O
         if (maxw <= 32) return small ? launch_fwd_uniform<1, true>(x, weights, biases, y, npix, P, d, s) : launch_fwd_uniform<1, false>(x, weights, biases, y, npix, P, d, s);
+        if (NNS_PM_PIPE && small) return launch_fwd_pipe4(x, weights, biases, y, npix, P, d, s);             // (generic I/O keeps the kernel above)
         return small ? launch_fwd_uniform<2, true>(x, weights, biases, y, npix, P, d, s) : launch_fwd_uniform<2, false>(x, weights, biases, y, npix, P, d, s);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
