@@ -12,6 +12,7 @@
 //     (The column pass itself reads and writes the [src|dest][F][B][nloc][ny/P] layout in place: segmented rows,
 //     nns_spec_residual_xpass_seg_f32.)
 #include "nns_common.h"
+#include <cstdint>
 
 using namespace nns;
 
@@ -72,6 +73,26 @@ __global__ __launch_bounds__(256) void transpose_kernel(Ptr4<T> rows_in, MPtr4<T
     if constexpr (PACK) buf[pk] = rows_in.p[f][row]; else rows_out.p[f][row] = buf[pk];
 }
 
+// The same copy, 16 bytes per thread and several row-lines per workgroup (round 3: one 4-byte element per thread and one 1-KB row piece per
+// workgroup moved the transposes of the 1024^2 x 64 slab at 2.9 TB/s -- 786 k tiny workgroups).  VW = elements per 16-byte vector; needs
+// ny / P a multiple of VW and 16-byte aligned fields and buffer (checked on the host).
+template <typename T, bool PACK>
+__global__ __launch_bounds__(256) void transpose_vec_kernel(Ptr4<T> rows_in, MPtr4<T> rows_out, T* __restrict__ buf, long B, long nloc, long ny, long P, long nlines) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    using V = __attribute__((ext_vector_type(VW))) T;
+    const long f = blockIdx.z, F = gridDim.z;
+    const long nyl = ny / P, vpr = ny / VW;                                  // vectors per row-line
+    const long total = nlines * vpr;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long bi = e / vpr, j = (e - bi * vpr) * VW;
+        const long d = j / nyl, jj = j - d * nyl;
+        const long row = bi * ny + j;
+        const long pk = ((d * F + f) * B * nloc + bi) * nyl + jj;
+        if constexpr (PACK) *reinterpret_cast<V*>(buf + pk) = *reinterpret_cast<const V*>(rows_in.p[f] + row);
+        else *reinterpret_cast<V*>(rows_out.p[f] + row) = *reinterpret_cast<const V*>(buf + pk);
+    }
+}
+
 template <typename T>
 int transpose(bool pack, const T* const* fields, int nfields, T* buf, int B, int nloc, int ny, int P, hipStream_t s) {
     if (!fields || !buf || nfields < 1 || nfields > 4 || B < 1 || nloc < 1 || ny < 1 || P < 1 || ny % P || (long)B * nloc > 0x7fffffffL)
@@ -80,6 +101,21 @@ int transpose(bool pack, const T* const* fields, int nfields, T* buf, int B, int
         if (!fields[f]) return fail(NNS_ERR_INVALID_ARG, "slab transpose: field %d is NULL", f);
     const long bi = (long)B * nloc;
     if (bi > 65535L * 32768L) return fail(NNS_ERR_UNSUPPORTED, "slab transpose: slab too tall");
+    {   // vector path
+        constexpr int VW = 16 / (int)sizeof(T);
+        bool vec = (ny / P) % VW == 0 && reinterpret_cast<uintptr_t>(buf) % 16 == 0;
+        for (int f = 0; f < nfields; ++f) vec = vec && reinterpret_cast<uintptr_t>(fields[f]) % 16 == 0;
+        if (vec) {
+            Ptr4<T> in{}; MPtr4<T> out{};
+            for (int f = 0; f < nfields; ++f) { in.p[f] = fields[f]; out.p[f] = const_cast<T*>(fields[f]); }
+            const long total = bi * (ny / VW);
+            long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384;       // grid-stride: ~64 workgroups per CU and field
+            const dim3 grid((unsigned)blocks, 1, (unsigned)nfields);
+            if (pack) hipLaunchKernelGGL((transpose_vec_kernel<T, true>), grid, dim3(256), 0, s, in, out, buf, (long)B, (long)nloc, (long)ny, (long)P, bi);
+            else hipLaunchKernelGGL((transpose_vec_kernel<T, false>), grid, dim3(256), 0, s, in, out, buf, (long)B, (long)nloc, (long)ny, (long)P, bi);
+            return check_launch(pack ? "slab_transpose_pack" : "slab_transpose_unpack");
+        }
+    }
     // blockIdx.y is limited to 65535: fold the excess of B * nloc into blockIdx.x strides is not needed below 65535 rows;
     // taller slabs go in chunks of 65535 row-lines
     for (long r0 = 0; r0 < bi; r0 += 65535) {

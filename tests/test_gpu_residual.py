@@ -604,3 +604,22 @@ def test_column_pass_segments_beyond_32bit_offsets(precise, gpu_device):
         for src in range(nx // seg):
             got = big_out[src * stride + k * per: src * stride + (k + 1) * per].view(B, seg, ny)
             assert torch.equal(got, ref[k][:, src * seg:(src + 1) * seg]), (k, src)
+
+
+@pytest.mark.parametrize('B,nloc,ny,P,dtype', [(3, 5, 64, 4, torch.float32), (2, 7, 24, 4, torch.float32), (1, 4, 30, 3, torch.float64), (2, 3, 16, 2, torch.float64),
+                                                 (4, 16, 1024, 8, torch.float32)])
+def test_slab_transpose_pack_unpack_kernels(B, nloc, ny, P, dtype, gpu_device):
+    """The all-to-all buffer layout [P][F][B][nloc][ny / P] against a torch restatement, both the 16-byte vector kernel (ny / P a multiple of the
+    vector width) and the element kernel (ny / P = 6: not), float32 and float64, and the round trip."""
+    from nns import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(B * ny + P)
+    fields = [torch.randn(B, nloc, ny, device='cuda', dtype=dtype, generator=g) for _ in range(3)]
+    nyl = ny // P
+    send = torch.empty(P, 3, B, nloc, nyl, device='cuda', dtype=dtype)
+    ops.slab_transpose_pack(fields, send, P)
+    want = torch.stack([torch.stack([f[:, :, d * nyl:(d + 1) * nyl] for f in fields]) for d in range(P)])
+    assert torch.equal(send, want)
+    back = [torch.zeros_like(f) for f in fields]
+    ops.slab_transpose_unpack(send, back, P)
+    for a, b in zip(back, fields):
+        assert torch.equal(a, b)
