@@ -562,6 +562,9 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 // before that barrier (layer l+1's).  The two role bodies are separate code paths (separate loops with matching barriers), so that the
 // register allocator sees two small live sets instead of their union.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef NNS_PMB_EXP
+#define NNS_PMB_EXP 0              // timing probes of the split backward (wrong results): 1 = chain waves read no weight fragments from LDS, 2 = no per-layer barriers, 3 = no weight-gradient MFMAs
+#endif
 template <int OT, bool SMALLIO>
 __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                                    const float* __restrict__ W, const float* __restrict__ Bv,
@@ -610,12 +613,14 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 if (l < nl) {
                     const unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
                     const unsigned char* imgA = imgD + U::IMG_BYTES;
-                    __syncthreads();                                            // layer l's images are written
+                    if (NNS_PMB_EXP != 2) __syncthreads();                      // layer l's images are written
+                    // the operand fragments of k-step kk + 1 are requested before the MFMA of k-step kk (round 3)
+                    bf16x8 fan = frag_pix<ROWB>(imgD, lane, ks0, 32 * bo), fbn = frag_pix<ROWB>(imgA, lane, ks0, 32 * bi);
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk) {
-                        const bf16x8 fa = frag_pix<ROWB>(imgD, lane, ks0 + kk, 32 * bo);
-                        const bf16x8 fb = frag_pix<ROWB>(imgA, lane, ks0 + kk, 32 * bi);
-                        gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                        const bf16x8 fa = fan, fb = fbn;
+                        if (kk + 1 < KS) { fan = frag_pix<ROWB>(imgD, lane, ks0 + kk + 1, 32 * bo); fbn = frag_pix<ROWB>(imgA, lane, ks0 + kk + 1, 32 * bi); }
+                        if (NNS_PMB_EXP != 3) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
                         if (kk & 1) __builtin_amdgcn_sched_barrier(0);
                         if (do_gb) {
                             const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
@@ -659,20 +664,31 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
         // ---------------- forward: afrag[l] = input fragments of layer l
         bf16x8 afrag[kMaxLayers][SS];
         load_frags<SS, SMALLIO>(x + (size_t)b * cin0 * P + p, (size_t)P, cin0, ok, h, afrag[0]);
+        // Weight fragments are requested ONE MFMA AHEAD of their use (round 3; probe: with no fragment reads at all the kernel takes 1.19 instead of
+        // 1.41 ms -- every MFMA of the chain used to wait for its own two LDS reads), across layer boundaries too.
+        bf16x8 wq = frag_w<ROWB>(lds, r, h, 0, 0);
 #pragma unroll
         for (int l = 0; l + 1 < kMaxLayers; ++l) {
             if (l + 1 < nl) {
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* wimg = lds + l * U::W_BYTES;
+                const unsigned char* wnext = lds + (l + 2 < nl ? l + 1 : l) * U::W_BYTES;          // the next recomputed layer's image (clamped)
                 const float* bl = reinterpret_cast<const float*>(bias0 + l * U::B_BYTES);
                 f32x16 acc[OT];
 #pragma unroll
-                for (int ot = 0; ot < OT; ++ot) {
+                for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[ot][i] = bl[32 * ot + acc_row(i, h)];
-#pragma unroll
-                    for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<ROWB>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
-                }
+                static_for<0, OT * SS>([&](auto ic) {
+                    constexpr int idx = decltype(ic)::value, ot = idx / SS, s2 = idx % SS;
+                    bf16x8 wn;
+                    if constexpr (idx + 1 < OT * SS) wn = frag_w<ROWB>(wimg, r, h, (idx + 1) / SS, (idx + 1) % SS);
+                    else wn = frag_w<ROWB>(wnext, r, h, 0, 0);
+                    acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? afrag[l][(s2 + 1) % SS] : wq, afrag[l][s2], acc[ot], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    wq = wn;
+                });
 #pragma unroll
                 for (int s = 0; s < SS; ++s) afrag[l + 1][s] = pack8<true>(acc[s >> 1], 8 * (s & 1));
             }
@@ -685,6 +701,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #pragma unroll
             for (int s = 0; s < SS; ++s) dfrag[s] = pack8<false>(dl[s >> 1], 8 * (s & 1));
         }
+        bf16x8 tq = frag_t<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, 0, 0);
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
             if (l < nl) {
@@ -692,12 +709,20 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 const unsigned char* wimg = lds + l * U::W_BYTES;
                 f32x16 nd[OT];
 #pragma unroll
-                for (int it = 0; it < OT; ++it) {
+                for (int it = 0; it < OT; ++it)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < SS; ++s) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<ROWB>(wimg, lane, s, 32 * it), dfrag[s], nd[it], 0, 0, 0);
-                }
+                const unsigned char* wprev = lds + (l > 0 ? l - 1 : 0) * U::W_BYTES;               // the next layer of the walk
+                static_for<0, OT * SS>([&](auto ic) {
+                    constexpr int idx = decltype(ic)::value, it = idx / SS, s2 = idx % SS;
+                    bf16x8 tn;
+                    if constexpr (idx + 1 < OT * SS) tn = frag_t<ROWB>(wimg, lane, (idx + 1) % SS, 32 * ((idx + 1) / SS));
+                    else tn = frag_t<ROWB>(wprev, lane, 0, 0);
+                    nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? dfrag[(s2 + 1) % SS] : tq, dfrag[s2], nd[it], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    tq = tn;
+                });
                 __builtin_amdgcn_sched_barrier(0);
                 unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
                 unsigned char* imgA = imgD + U::IMG_BYTES;
@@ -712,7 +737,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                         *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
                     }
                 }
-                __syncthreads();                                                // layer l's images are written: over to the gradient waves
+                if (NNS_PMB_EXP != 2) __syncthreads();                          // layer l's images are written: over to the gradient waves
                 if (l > 0) {
 #pragma unroll
                     for (int s = 0; s < SS; ++s) dfrag[s] = pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
