@@ -582,7 +582,19 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
             const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
             const float* Wl = W + d.woff[l];
             unsigned char* dst = lds + l * U::W_BYTES;
-            for (int e = threadIdx.x; e < n; e += 512) *reinterpret_cast<unsigned short*>(dst + (e / cin) * ROWB + (e % cin) * 2) = f2bf(Wl[e]);
+            {   // eight reads in flight per thread and round (a dependent L2 round trip per element otherwise: see stage_uniform)
+                const unsigned magic = ((1u << 20) + (unsigned)cin - 1u) / (unsigned)cin;     // e / cin = (e * magic) >> 20, exact for e < 64 cin
+                for (int e0 = threadIdx.x; e0 < n; e0 += 8 * 512) {
+                    float vq[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int e = e0 + q * 512; vq[q] = Wl[e < n ? e : n - 1]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = e0 + q * 512;
+                        if (e < n) { const int row = (int)(((unsigned)e * magic) >> 20); *reinterpret_cast<unsigned short*>(dst + row * ROWB + (e - row * cin) * 2) = f2bf(vq[q]); }
+                    }
+                }
+            }
             float* bl = reinterpret_cast<float*>(lds + nl * U::W_BYTES + l * U::B_BYTES);
             for (int e = threadIdx.x; e < cout; e += 512) bl[e] = Bv[d.boff[l] + e];
         }
@@ -894,12 +906,33 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_f32_kernel(const float* __r
     }
 }
 
-__global__ void pixel_mlp_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gB, int nslices, int nparams_w, int nparams) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nparams) return;
+// Sum of the per-workgroup gradient slices in a FIXED order (deterministic): a workgroup owns 64 parameters; thread (part q, parameter i) adds
+// slices q, q + 16, q + 32, ... (loads of a round independent of each other: in flight together), then the 16 partial sums are added in order
+// of q.  (Round 3: one thread per parameter walking all 256 slices one dependent load at a time took 62 us for 34 MB.)
+constexpr int kRedParts = 16, kRedParams = 64;
+__global__ __launch_bounds__(kRedParts * kRedParams) void pixel_mlp_reduce_kernel(const float* __restrict__ ws, float* __restrict__ gW, float* __restrict__ gB,
+                                                                               int nslices, int nparams_w, int nparams) {
+    __shared__ float part[kRedParts][kRedParams];
+    const int il = threadIdx.x % kRedParams, q = threadIdx.x / kRedParams;
+    const int i = blockIdx.x * kRedParams + il;
     float acc = 0.f;
-    for (int k = 0; k < nslices; ++k) acc += ws[(size_t)k * nparams + i];
-    if (i < nparams_w) gW[i] = acc; else gB[i - nparams_w] = acc;
+    if (i < nparams) {
+        int k = q;
+        for (; k + 3 * kRedParts < nslices; k += 4 * kRedParts) {
+            const float a0 = ws[(size_t)k * nparams + i], a1 = ws[(size_t)(k + kRedParts) * nparams + i];
+            const float a2 = ws[(size_t)(k + 2 * kRedParts) * nparams + i], a3 = ws[(size_t)(k + 3 * kRedParts) * nparams + i];
+            acc = (((acc + a0) + a1) + a2) + a3;
+        }
+        for (; k < nslices; k += kRedParts) acc += ws[(size_t)k * nparams + i];
+    }
+    part[q][il] = acc;
+    __syncthreads();
+    if (q == 0 && i < nparams) {
+        float t = part[0][il];
+#pragma unroll
+        for (int j = 1; j < kRedParts; ++j) t += part[j][il];
+        if (i < nparams_w) gW[i] = t; else gB[i - nparams_w] = t;
+    }
 }
 
 constexpr int kBwdMaxBlocks = 256;
@@ -931,7 +964,7 @@ int launch_bwd_f32(const float* x, const float* gy, const float* weights, const 
     const int blocks = (int)(nsuper < kBwdMaxBlocks ? nsuper : kBwdMaxBlocks);
     hipLaunchKernelGGL((pixel_mlp_bwd_f32_kernel<SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
     if (int rc = check_launch("pixel_mlp_bwd")) return rc;
-    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((nparams + 255) / 256), dim3(256), 0, s, ws, gW, gB, blocks * 4, nparams_w, nparams);
+    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((nparams + kRedParams - 1) / kRedParams), dim3(kRedParts * kRedParams), 0, s, ws, gW, gB, blocks * 4, nparams_w, nparams);
     return check_launch("pixel_mlp_reduce");
 }
 
@@ -955,7 +988,7 @@ int launch_bwd_uniform(const float* x, const float* gy, const float* weights, co
     hipLaunchKernelGGL((pixel_mlp_bwd_uniform_kernel<OT, SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
     if (int rc = check_launch("pixel_mlp_bwd")) return rc;
     const int nslices = blocks * (OT == 2 ? 1 : 4);
-    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((nparams + 255) / 256), dim3(256), 0, s, ws, gW, gB, nslices, nparams_w, nparams);
+    hipLaunchKernelGGL(pixel_mlp_reduce_kernel, dim3((nparams + kRedParams - 1) / kRedParams), dim3(kRedParts * kRedParams), 0, s, ws, gW, gB, nslices, nparams_w, nparams);
     return check_launch("pixel_mlp_reduce");
 }
 
