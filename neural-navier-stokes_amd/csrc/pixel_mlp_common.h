@@ -83,10 +83,10 @@ __device__ inline void stage_uniform(const PixelMlpDesc& d, const float* __restr
         const int cin = d.cin[l], cout = d.cout[l], n = cin * cout;
         const float* Wl = W + d.woff[l];
         unsigned short* dst = reinterpret_cast<unsigned short*>(lds + l * U::W_BYTES);
-        // Eight elements per thread and round, all eight global reads in flight before the first LDS write (round 3: one read per loop
+        // UNR elements per thread and round, all their global reads in flight before the first LDS write (round 3: one read per loop
         // iteration, each waited for before its 2-byte LDS write, made the staging of a depth-8 width-64 stack 128 dependent L2 round trips:
         // 32 us of a 280 us kernel, tools/pm_kernel_times.sh).
-        constexpr int UNR = 8;
+        constexpr int UNR = 8;            // (32 per round measured the same)
         const unsigned magic = ((1u << 20) + (unsigned)cin - 1u) / (unsigned)cin;        // e / cin = (e * magic) >> 20, exact for e < 64 cin (cin <= 64)
         for (int e0 = tid; e0 < n; e0 += UNR * nthreads) {
             float v[UNR];

@@ -21,7 +21,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kP4Threads = 256;
 __global__ __launch_bounds__(kP4Threads) __attribute__((amdgpu_waves_per_eu(1, 1))) void pixel_mlp_fwd_pipe4_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
-                                                                        float* __restrict__ y, long npix_total, int P, PixelMlpDesc d) {
+                                                                        float* __restrict__ y, long npix_total, int P, PixelMlpDesc d, unsigned pmagic, int pshift) {
     constexpr int OT = 2, SS = 4, NF = OT * SS, NT = 4;
     using U = UniLds<OT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -40,6 +40,15 @@ __global__ __launch_bounds__(kP4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
     bf16x8 w[NF];
 #pragma unroll
     for (int idx = 0; idx < NF; ++idx) w[idx] = wl0[idx * 64];
+    // pixel index -> (image, pixel in image): division by the runtime P with a host-made multiplier (exact for every 32-bit index; the 64-bit
+    // `gp / P`, `gp % P` of the first version were ~150 emulated-division instructions per tile, eight times per group of 128 pixels)
+    auto split = [&](long gp, long& img, long& pix) {
+        if (pshift >= 0) {
+            const unsigned n = (unsigned)gp, t = __umulhi(pmagic, n);
+            const unsigned q = (t + ((n - t) >> 1)) >> pshift;
+            img = q; pix = n - q * (unsigned)P;
+        } else { img = gp / P; pix = gp % P; }
+    };
     // raw inputs of a group: channel j < cin0 of this lane's pixel of every tile (unconditional, clamped loads)
     float xin[NT][4];
     auto load_raw = [&](long g) {
@@ -47,7 +56,9 @@ __global__ __launch_bounds__(kP4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int t = 0; t < NT; ++t) {
             const long gp = (g * NT + t) * 32 + r;
             const long gc = gp < npix_total ? gp : npix_total - 1;
-            const float* xb = x + (size_t)(gc / P) * cin0 * P + gc % P;
+            long bimg, pimg;
+            split(gc, bimg, pimg);
+            const float* xb = x + (size_t)bimg * cin0 * P + pimg;
 #pragma unroll
             for (int j = 0; j < 4; ++j) xin[t][j] = xb[(size_t)(j < cin0 ? j : 0) * P];
         }
@@ -146,7 +157,11 @@ __global__ __launch_bounds__(kP4Threads) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const long gp = (g * NT + t) * 32 + r;
-            if (gp < npix_total) store_acc<OT, true>(y + (size_t)(gp / P) * coutL * P + gp % P, (size_t)P, coutL, h, acc[t]);
+            if (gp < npix_total) {
+                long bimg, pimg;
+                split(gp, bimg, pimg);
+                store_acc<OT, true>(y + (size_t)bimg * coutL * P + pimg, (size_t)P, coutL, h, acc[t]);
+            }
         }
     }
 }
@@ -162,7 +177,14 @@ int nns::pm::launch_fwd_pipe4(const float* x, const float* weights, const float*
     int cus = 256;
     { int dev = 0, v = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     long blocks = (ngroups + 3) / 4; if (blocks > cus) blocks = cus;       // persistent: one workgroup (four waves, one per SIMD) per CU
-    hipLaunchKernelGGL(pixel_mlp_fwd_pipe4_kernel, dim3((unsigned)blocks), dim3(kP4Threads), lds, s, x, weights, biases, y, npix, P, d);
+    // n / P for 32-bit n:  t = umulhi(m, n);  q = (t + ((n - t) >> 1)) >> (l - 1)  with l = ceil(log2 P), m = floor(2^32 (2^l - P) / P) + 1
+    unsigned pmagic = 0; int pshift = -1;
+    if (npix < (1L << 32) && P >= 2) {
+        int l = 0; while ((1L << l) < P) ++l;
+        pmagic = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << l) - (unsigned long long)P)) / (unsigned long long)P + 1);
+        pshift = l - 1;
+    }
+    hipLaunchKernelGGL(pixel_mlp_fwd_pipe4_kernel, dim3((unsigned)blocks), dim3(kP4Threads), lds, s, x, weights, biases, y, npix, P, d, pmagic, pshift);
     return check_launch("pixel_mlp_fwd");
 }
 
