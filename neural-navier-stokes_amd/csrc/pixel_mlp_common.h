@@ -39,11 +39,11 @@ __device__ __forceinline__ int pack2(float a, float b) {
     if constexpr (RELU) q = __builtin_elementwise_max(q, (s16x2v){0, 0});
     return __builtin_bit_cast(int, q);
 }
-// ReLU' mask of the backward chain: keep the halves of `v` (two packed bf16) whose activation in `act` (two packed bf16, >= 0) is non-zero
-using u16x2v = __attribute__((ext_vector_type(2))) unsigned short;
+// ReLU' mask of the backward chain: keep the halves of `v` (two packed bf16) whose activation in `act` (two packed bf16, >= 0) is non-zero.
+// Written as (0 - act) >> 15 on packed int16 (v_pk_sub_i16, v_pk_ashrrev_i16, v_and: three instructions per pair); the min / negate
+// and multiply forms are "recognised" by the compiler as selects and come out as two compares, two conditional moves and a v_perm per pair.
 __device__ __forceinline__ int mask2(int v, int act) {
-    const u16x2v one = {1, 1}, zero = {0, 0};
-    const u16x2v m = zero - __builtin_elementwise_min(__builtin_bit_cast(u16x2v, act), one);          // 0xFFFF where the activation is non-zero, else 0
+    const s16x2v m = ((s16x2v){0, 0} - __builtin_bit_cast(s16x2v, act)) >> (s16x2v){15, 15};
     return v & __builtin_bit_cast(int, m);
 }
 template <bool RELU_UNUSED = false>

@@ -562,8 +562,17 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 // before that barrier (layer l+1's).  The two role bodies are separate code paths (separate loops with matching barriers), so that the
 // register allocator sees two small live sets instead of their union.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef NNS_PMB_DEPTH
+#define NNS_PMB_DEPTH 4            // operand fragments in flight per MFMA stream of the split backward
+#endif
+constexpr int kBwdDepth = NNS_PMB_DEPTH;
+#ifndef NNS_PMB_ALT
+#define NNS_PMB_ALT 0              // 1: the data chain's MFMAs alternate between the two accumulators
+#endif
+constexpr bool kBwdAlt = NNS_PMB_ALT != 0;
 #ifndef NNS_PMB_EXP
-#define NNS_PMB_EXP 0              // timing probes of the split backward (wrong results): 1 = chain waves read no weight fragments from LDS, 2 = no per-layer barriers, 3 = no weight-gradient MFMAs
+#define NNS_PMB_EXP 0              // timing probes of the split backward (wrong results): 1 = chain waves read no weight fragments from LDS, 2 = no per-layer barriers, 3 = no weight-gradient MFMAs,
+                                   // 4 = gradient waves only keep the barriers, 5 = no forward recompute, 6 = no image writes, 7 = no ReLU' mask
 #endif
 template <int OT, bool SMALLIO>
 __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ gy,
@@ -626,13 +635,18 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     const unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
                     const unsigned char* imgA = imgD + U::IMG_BYTES;
                     if (NNS_PMB_EXP != 2) __syncthreads();                      // layer l's images are written
-                    // the operand fragments of k-step kk + 1 are requested before the MFMA of k-step kk (round 3)
-                    bf16x8 fan = frag_pix<ROWB>(imgD, lane, ks0, 32 * bo), fbn = frag_pix<ROWB>(imgA, lane, ks0, 32 * bi);
+                    if (NNS_PMB_EXP == 4) continue;
+                    // the operand fragments of k-step kk + GD are requested before the MFMA of k-step kk (round 3: an LDS read takes longer than
+                    // one MFMA, so one step ahead still left every MFMA waiting)
+                    constexpr int GD = KS < kBwdDepth ? KS : kBwdDepth;
+                    bf16x8 fa_r[GD], fb_r[GD];
+#pragma unroll
+                    for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<ROWB>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<ROWB>(imgA, lane, ks0 + q, 32 * bi); }
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk) {
-                        const bf16x8 fa = fan, fb = fbn;
-                        if (kk + 1 < KS) { fan = frag_pix<ROWB>(imgD, lane, ks0 + kk + 1, 32 * bo); fbn = frag_pix<ROWB>(imgA, lane, ks0 + kk + 1, 32 * bi); }
+                        const bf16x8 fa = fa_r[kk % GD], fb = fb_r[kk % GD];
                         if (NNS_PMB_EXP != 3) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                        if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<ROWB>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<ROWB>(imgA, lane, ks0 + kk + GD, 32 * bi); }
                         if (kk & 1) __builtin_amdgcn_sched_barrier(0);
                         if (do_gb) {
                             const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
@@ -676,31 +690,47 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
         // ---------------- forward: afrag[l] = input fragments of layer l
         bf16x8 afrag[kMaxLayers][SS];
         load_frags<SS, SMALLIO>(x + (size_t)b * cin0 * P + p, (size_t)P, cin0, ok, h, afrag[0]);
-        // Weight fragments are requested ONE MFMA AHEAD of their use (round 3; probe: with no fragment reads at all the kernel takes 1.19 instead of
-        // 1.41 ms -- every MFMA of the chain used to wait for its own two LDS reads), across layer boundaries too.
-        bf16x8 wq = frag_w<ROWB>(lds, r, h, 0, 0);
+        // Weight fragments are requested kBwdDepth MFMAs AHEAD of their use, across layer boundaries too (round 3; probe: with no fragment
+        // reads at all the kernel takes 1.06 instead of 1.37 ms -- an LDS read issued by one wave per SIMD takes ~100 cycles, three MFMAs).
+        constexpr int NM = OT * SS, D = kBwdDepth < NM ? kBwdDepth : NM;
+        static_assert(NM % D == 0, "ring slots must line up across layers");
+        bf16x8 wr[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) wr[q] = frag_w<ROWB>(lds, r, h, q / SS, q % SS);
+        f32x16 accb[2][OT];                                                                        // accumulators by layer parity: the other set takes the next bias
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accb[0][ot][i] = reinterpret_cast<const float*>(bias0)[32 * ot + acc_row(i, h)];
 #pragma unroll
         for (int l = 0; l + 1 < kMaxLayers; ++l) {
             if (l + 1 < nl) {
+                if (NNS_PMB_EXP == 5) {
+#pragma unroll
+                    for (int s = 0; s < SS; ++s) afrag[l + 1][s] = afrag[l][s];
+                    continue;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* wimg = lds + l * U::W_BYTES;
                 const unsigned char* wnext = lds + (l + 2 < nl ? l + 1 : l) * U::W_BYTES;          // the next recomputed layer's image (clamped)
-                const float* bl = reinterpret_cast<const float*>(bias0 + l * U::B_BYTES);
-                f32x16 acc[OT];
-#pragma unroll
-                for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[ot][i] = bl[32 * ot + acc_row(i, h)];
-                static_for<0, OT * SS>([&](auto ic) {
-                    constexpr int idx = decltype(ic)::value, ot = idx / SS, s2 = idx % SS;
-                    bf16x8 wn;
-                    if constexpr (idx + 1 < OT * SS) wn = frag_w<ROWB>(wimg, r, h, (idx + 1) / SS, (idx + 1) % SS);
-                    else wn = frag_w<ROWB>(wnext, r, h, 0, 0);
-                    acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? afrag[l][(s2 + 1) % SS] : wq, afrag[l][s2], acc[ot], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                f32x16 (&acc)[OT] = accb[l & 1];                                                   // holds this layer's bias already
+                f32x16 (&accn)[OT] = accb[(l + 1) & 1];
+                static_for<0, NM>([&](auto ic) {
+                    constexpr int idx = decltype(ic)::value, ot = idx / SS, s2 = idx % SS, nx = idx + D;
+                    acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? afrag[l][(s2 + 1) % SS] : wr[idx % D], afrag[l][s2], acc[ot], 0, 0, 0);
+                    if constexpr (nx < NM) wr[idx % D] = frag_w<ROWB>(wimg, r, h, nx / SS, nx % SS);
+                    else wr[idx % D] = frag_w<ROWB>(wnext, r, h, (nx - NM) / SS, (nx - NM) % SS);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              // a frag_w is one ds_read2_b64
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    wq = wn;
                 });
+                {   // the next layer's bias, requested under this layer's conversion (a read placed at its use is the youngest in the queue: lgkmcnt(0))
+                    const float* bn = reinterpret_cast<const float*>(bias0 + (l + 2 < nl ? l + 1 : l) * U::B_BYTES);
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) accn[ot][i] = bn[32 * ot + acc_row(i, h)];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4 * OT, 0);
+                }
 #pragma unroll
                 for (int s = 0; s < SS; ++s) afrag[l + 1][s] = pack8<true>(acc[s >> 1], 8 * (s & 1));
             }
@@ -713,7 +743,9 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #pragma unroll
             for (int s = 0; s < SS; ++s) dfrag[s] = pack8<false>(dl[s >> 1], 8 * (s & 1));
         }
-        bf16x8 tq = frag_t<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, 0, 0);
+        bf16x8 tr[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) tr[q] = frag_t<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, kBwdAlt ? q / OT : q % SS, 32 * (kBwdAlt ? q % OT : q / SS));
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
             if (l < nl) {
@@ -725,34 +757,35 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #pragma unroll
                     for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
                 const unsigned char* wprev = lds + (l > 0 ? l - 1 : 0) * U::W_BYTES;               // the next layer of the walk
-                static_for<0, OT * SS>([&](auto ic) {
-                    constexpr int idx = decltype(ic)::value, it = idx / SS, s2 = idx % SS;
-                    bf16x8 tn;
-                    if constexpr (idx + 1 < OT * SS) tn = frag_t<ROWB>(wimg, lane, (idx + 1) % SS, 32 * ((idx + 1) / SS));
-                    else tn = frag_t<ROWB>(wprev, lane, 0, 0);
-                    nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? dfrag[(s2 + 1) % SS] : tq, dfrag[s2], nd[it], 0, 0, 0);
+                // delta_l and a_{l-1} are known on entry: their image rows are stored UNDER the layer's MFMAs (the set is free once the barrier of
+                // layer l + 1 is behind this wave), so that only the barrier itself stands between the last MFMA and the mask / convert step.
+                unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
+                unsigned char* rowD = imgD + (32 * wave + r) * ROWB + 8 * h;
+                unsigned char* rowA = rowD + U::IMG_BYTES;
+                static_for<0, NM>([&](auto ic) {
+                    constexpr int idx = decltype(ic)::value, it = kBwdAlt ? idx % OT : idx / SS, s2 = kBwdAlt ? idx / OT : idx % SS, nx = idx + D;
+                    constexpr int nit = kBwdAlt ? nx % OT : (nx % NM) / SS, ns2 = kBwdAlt ? (nx % NM) / OT : nx % SS;
+                    nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? dfrag[(s2 + 1) % SS] : tr[idx % D], dfrag[s2], nd[it], 0, 0, 0);
+                    tr[idx % D] = frag_t<ROWB>(nx < NM ? wimg : wprev, lane, ns2, 32 * nit);
+                    constexpr int per = 4 * SS / NM;                                                // 8-byte image stores per MFMA
+                    if (NNS_PMB_EXP != 6) {
+#pragma unroll
+                        for (int j = 0; j < per; ++j) {
+                            const int k = idx * per + j, s = k >> 2;
+                            const bf16x8 src = (k & 2) ? afrag[l][s] : dfrag[s];
+                            unsigned char* row = (k & 2) ? rowA : rowD;
+                            *reinterpret_cast<bf16x4*>(row + (16 * s + 8 * (k & 1)) * 2) = (k & 1) ? __builtin_shufflevector(src, src, 4, 5, 6, 7) : __builtin_shufflevector(src, src, 0, 1, 2, 3);
+                        }
+                    }
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (NNS_PMB_EXP != 6) __builtin_amdgcn_sched_group_barrier(0x200, per, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    tq = tn;
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
-                unsigned char* imgA = imgD + U::IMG_BYTES;
-                {
-                    unsigned char* rowD = imgD + (32 * wave + r) * ROWB;
-                    unsigned char* rowA = imgA + (32 * wave + r) * ROWB;
-#pragma unroll
-                    for (int s = 0; s < SS; ++s) {
-                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 0, 1, 2, 3);
-                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
-                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 0, 1, 2, 3);
-                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
-                    }
-                }
                 if (NNS_PMB_EXP != 2) __syncthreads();                          // layer l's images are written: over to the gradient waves
                 if (l > 0) {
 #pragma unroll
-                    for (int s = 0; s < SS; ++s) dfrag[s] = pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
+                    for (int s = 0; s < SS; ++s) dfrag[s] = NNS_PMB_EXP == 7 ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
                 } else if (ok) {
                     store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
