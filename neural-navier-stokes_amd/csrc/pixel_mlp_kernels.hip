@@ -566,6 +566,12 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 #define NNS_PMB_DEPTH 4            // operand fragments in flight per MFMA stream of the split backward
 #endif
 constexpr int kBwdDepth = NNS_PMB_DEPTH;
+#ifndef NNS_PMB_TIMING
+#define NNS_PMB_TIMING 0           // 1: the two-tile kernel prints the cycles of one super-tile's forward and backward halves (wave 0 of workgroup 0)
+#endif
+#ifndef NNS_PMB_PRIO
+#define NNS_PMB_PRIO 0
+#endif
 #ifndef NNS_PMB_ALT
 #define NNS_PMB_ALT 0              // 1: the data chain's MFMAs alternate between the two accumulators
 #endif
@@ -574,16 +580,15 @@ constexpr bool kBwdAlt = NNS_PMB_ALT != 0;
 #define NNS_PMB_EXP 0              // timing probes of the split backward (wrong results): 1 = chain waves read no weight fragments from LDS, 2 = no per-layer barriers, 3 = no weight-gradient MFMAs,
                                    // 4 = gradient waves only keep the barriers, 5 = no forward recompute, 6 = no image writes, 7 = no ReLU' mask
 #endif
-template <int OT, bool SMALLIO>
-__global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                   const float* __restrict__ W, const float* __restrict__ Bv,
-                                                                   float* __restrict__ gx, float* __restrict__ ws,
-                                                                   long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
+#define PMB(k) (((NNS_PMB_EXP) >> ((k) - 1)) & 1)     // probe k is bit k-1 of NNS_PMB_EXP, so that probes combine; 8 / 9: forward / backward conversion replaced by a register reinterpretation
+__device__ __forceinline__ bf16x8 raw8(const f32x16& a, int base) { const i32x4v r = {__builtin_bit_cast(int, a[base]), __builtin_bit_cast(int, a[base + 1]), __builtin_bit_cast(int, a[base + 2]), __builtin_bit_cast(int, a[base + 3])}; return __builtin_bit_cast(bf16x8, r); }
+// Staging of the split backward kernels: zero everything (pads, images), then scatter the real matrices (coalesced reads).  512 threads.
+template <int OT>
+__device__ __forceinline__ void bwd_stage(unsigned char* lds, const float* __restrict__ W, const float* __restrict__ Bv, const PixelMlpDesc& d) {
     using U = BwdLds<OT>;
-    constexpr int SS = U::SS, ROWB = U::ROWB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int ROWB = U::ROWB;
     const int nl = d.nlayers;
-    {   // stage: zero everything (pads, images), then scatter the real matrices (coalesced reads)
+    {
         const int total = U::total(nl);
         for (int e = threadIdx.x; e < total / 16; e += 512) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
@@ -609,86 +614,136 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
         }
         __syncthreads();
     }
+}
+
+// The GRADIENT waves of the split backward kernels (waves 4..7 of the workgroup): see pixel_mlp_bwd_split_kernel.
+template <int OT>
+__device__ __forceinline__ void bwd_gradient_waves(unsigned char* img0, int wave, int lane, long nsuper, const PixelMlpDesc& d,
+                                                   float* __restrict__ ws, int nparams_w, int nparams) {
+    using U = BwdLds<OT>;
+    constexpr int ROWB = U::ROWB;
+    const int nl = d.nlayers, r = lane & 31, h = lane >> 5;
+    // ================= gradient waves =================
+    const int gwv = wave - 4;
+    const int bo = OT == 2 ? gwv >> 1 : 0, bi = OT == 2 ? gwv & 1 : 0;     // this wave's gW block
+    constexpr int KS = OT == 2 ? 8 : 2;                                     // its k-steps (of 8 x 16 pixels)
+    const int ks0 = OT == 2 ? 0 : 2 * gwv;
+    const bool do_gb = OT == 2 ? bi == 0 : true;
+    f32x16 gw[kMaxLayers];
+    float gbp[kMaxLayers];
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        gbp[l] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gw[l][i] = 0.f;
+    }
+    for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+#pragma unroll
+        for (int l = kMaxLayers - 1; l >= 0; --l) {
+            if (l < nl) {
+                const unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
+                const unsigned char* imgA = imgD + U::IMG_BYTES;
+                if (!PMB(2)) __syncthreads();                      // layer l's images are written
+                if (PMB(4)) continue;
+                // the operand fragments of k-step kk + GD are requested before the MFMA of k-step kk (round 3: an LDS read takes longer than
+                // one MFMA, so one step ahead still left every MFMA waiting)
+                constexpr int GD = KS < kBwdDepth ? KS : kBwdDepth;
+                bf16x8 fa_r[GD], fb_r[GD];
+#pragma unroll
+                for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<ROWB>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<ROWB>(imgA, lane, ks0 + q, 32 * bi); }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 fa = fa_r[kk % GD], fb = fb_r[kk % GD];
+                    if (!PMB(3)) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                    if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<ROWB>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<ROWB>(imgA, lane, ks0 + kk + GD, 32 * bi); }
+                    if (kk & 1) __builtin_amdgcn_sched_barrier(0);
+                    if (do_gb) {
+                        const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const unsigned pr = (unsigned)(unsigned short)fa[j] | ((unsigned)(unsigned short)fa[j + 1] << 16);
+                            gbp[l] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pr), ones, gbp[l], false);
+                        }
+                    }
+                }
+            }
+        }
+        if (nl & 1) __syncthreads();                                        // end of the super-tile: see the chain waves
+    }
+    float* wsb = ws + (size_t)(OT == 2 ? blockIdx.x : blockIdx.x * 4 + gwv) * nparams;
+#pragma unroll
+    for (int l = 0; l < kMaxLayers; ++l) {
+        if (l < nl) {
+            const int cin = d.cin[l], cout = d.cout[l];
+            const int in = 32 * bi + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int out = 32 * bo + acc_row(i, h);
+                if (out < cout && in < cin) wsb[d.woff[l] + out * cin + in] = gw[l][i];
+            }
+            if (do_gb) {
+                const float tot = gbp[l] + __shfl_xor(gbp[l], 32);
+                if (h == 0 && 32 * bo + r < cout) wsb[nparams_w + d.boff[l] + 32 * bo + r] = tot;
+            }
+        }
+    }
+}
+
+template <int OT, bool SMALLIO>
+__global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                   const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                   float* __restrict__ gx, float* __restrict__ ws,
+                                                                   long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
+    using U = BwdLds<OT>;
+    constexpr int SS = U::SS, ROWB = U::ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nl = d.nlayers;
+    bwd_stage<OT>(lds, W, Bv, d);
     const unsigned char* bias0 = lds + nl * U::W_BYTES;
     unsigned char* img0 = lds + nl * (U::W_BYTES + U::B_BYTES);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave, r = lane & 31, h = lane >> 5;
     const long nsuper = (npix_total + 127) / 128;
     if (wave >= 4) {
-        // ================= gradient waves =================
-        const int gwv = wave - 4;
-        const int bo = OT == 2 ? gwv >> 1 : 0, bi = OT == 2 ? gwv & 1 : 0;     // this wave's gW block
-        constexpr int KS = OT == 2 ? 8 : 2;                                     // its k-steps (of 8 x 16 pixels)
-        const int ks0 = OT == 2 ? 0 : 2 * gwv;
-        const bool do_gb = OT == 2 ? bi == 0 : true;
-        f32x16 gw[kMaxLayers];
-        float gbp[kMaxLayers];
-#pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) {
-            gbp[l] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) gw[l][i] = 0.f;
-        }
-        for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
-#pragma unroll
-            for (int l = kMaxLayers - 1; l >= 0; --l) {
-                if (l < nl) {
-                    const unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
-                    const unsigned char* imgA = imgD + U::IMG_BYTES;
-                    if (NNS_PMB_EXP != 2) __syncthreads();                      // layer l's images are written
-                    if (NNS_PMB_EXP == 4) continue;
-                    // the operand fragments of k-step kk + GD are requested before the MFMA of k-step kk (round 3: an LDS read takes longer than
-                    // one MFMA, so one step ahead still left every MFMA waiting)
-                    constexpr int GD = KS < kBwdDepth ? KS : kBwdDepth;
-                    bf16x8 fa_r[GD], fb_r[GD];
-#pragma unroll
-                    for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<ROWB>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<ROWB>(imgA, lane, ks0 + q, 32 * bi); }
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) {
-                        const bf16x8 fa = fa_r[kk % GD], fb = fb_r[kk % GD];
-                        if (NNS_PMB_EXP != 3) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
-                        if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<ROWB>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<ROWB>(imgA, lane, ks0 + kk + GD, 32 * bi); }
-                        if (kk & 1) __builtin_amdgcn_sched_barrier(0);
-                        if (do_gb) {
-                            const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-                            for (int j = 0; j < 8; j += 2) {
-                                const unsigned pr = (unsigned)(unsigned short)fa[j] | ((unsigned)(unsigned short)fa[j + 1] << 16);
-                                gbp[l] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pr), ones, gbp[l], false);
-                            }
-                        }
-                    }
-                }
-            }
-            if (nl & 1) __syncthreads();                                        // end of the super-tile: see the chain waves
-        }
-        float* wsb = ws + (size_t)(OT == 2 ? blockIdx.x : blockIdx.x * 4 + gwv) * nparams;
-#pragma unroll
-        for (int l = 0; l < kMaxLayers; ++l) {
-            if (l < nl) {
-                const int cin = d.cin[l], cout = d.cout[l];
-                const int in = 32 * bi + r;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int out = 32 * bo + acc_row(i, h);
-                    if (out < cout && in < cin) wsb[d.woff[l] + out * cin + in] = gw[l][i];
-                }
-                if (do_gb) {
-                    const float tot = gbp[l] + __shfl_xor(gbp[l], 32);
-                    if (h == 0 && 32 * bo + r < cout) wsb[nparams_w + d.boff[l] + 32 * bo + r] = tot;
-                }
-            }
-        }
+        bwd_gradient_waves<OT>(img0, wave, lane, nsuper, d, ws, nparams_w, nparams);
         return;
     }
     // ================= chain waves =================
+    if (NNS_PMB_PRIO) __builtin_amdgcn_s_setprio(NNS_PMB_PRIO);                 // the chain is the critical path; the gradient waves fill its gaps
     const int cin0 = d.cin[0], coutL = d.cout[nl - 1];
+    // this lane's pixel in a super-tile: in range?, batch entry, pixel within the field
+    auto locate = [&](long sup_, bool& ok_, int& b_, int& p_) {
+        const long gp = sup_ * 128 + wave * 32 + r;
+        ok_ = gp < npix_total;
+        const long gc = ok_ ? gp : npix_total - 1;
+        if (npix_total <= 0x7fffffffL) { const unsigned q = (unsigned)gc / (unsigned)P; b_ = (int)q; p_ = (int)((unsigned)gc - q * (unsigned)P); }
+        else { b_ = (int)(gc / P); p_ = (int)(gc % P); }
+    };
+    // SMALLIO: channels 0..3 of a [channel][pixel] field, unconverted, so that the load can stay in flight (lane half 0 holds them)
+    // (the values are masked where they are USED: a select next to the load would wait for it)
+    auto raw4 = [&](const float* __restrict__ fb, int nch, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fb[(size_t)(i < nch ? i : 0) * P];
+    };
+    // Round 3: a super-tile used to START with its x loads and its backward walk with its gy loads -- two exposed HBM round trips
+    // (~10 k of ~21 k cycles per super-tile, measured with s_memtime).  Now gy is requested before the forward recompute and the NEXT
+    // super-tile's x before the backward walk.
+    bool okn = false; int bn_ = 0, pn_ = 0; float xr[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SMALLIO) { locate(blockIdx.x, okn, bn_, pn_); raw4(x + (size_t)bn_ * cin0 * P + pn_, cin0, xr); }
     for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
-        const long gp = sup * 128 + wave * 32 + r;
-        const bool ok = gp < npix_total;
-        const long gc = ok ? gp : npix_total - 1;
-        const long b = gc / P, p = gc % P;
+        bool ok; int b, p;
+        if constexpr (SMALLIO) { ok = okn; b = bn_; p = pn_; } else locate(sup, ok, b, p);
         // ---------------- forward: afrag[l] = input fragments of layer l
         bf16x8 afrag[kMaxLayers][SS];
+        float gr[4];
+        if constexpr (SMALLIO) {
+#pragma unroll
+            for (int s = 0; s < SS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) afrag[0][s][j] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) afrag[0][0][j] = (short)f2bf((ok && h == 0 && j < cin0) ? xr[j] : 0.f);
+            raw4(gy + (size_t)b * coutL * P + p, coutL, gr);
+        } else
         load_frags<SS, SMALLIO>(x + (size_t)b * cin0 * P + p, (size_t)P, cin0, ok, h, afrag[0]);
         // Weight fragments are requested kBwdDepth MFMAs AHEAD of their use, across layer boundaries too (round 3; probe: with no fragment
         // reads at all the kernel takes 1.06 instead of 1.37 ms -- an LDS read issued by one wave per SIMD takes ~100 cycles, three MFMAs).
@@ -705,7 +760,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #pragma unroll
         for (int l = 0; l + 1 < kMaxLayers; ++l) {
             if (l + 1 < nl) {
-                if (NNS_PMB_EXP == 5) {
+                if (PMB(5)) {
 #pragma unroll
                     for (int s = 0; s < SS; ++s) afrag[l + 1][s] = afrag[l][s];
                     continue;
@@ -717,7 +772,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 f32x16 (&accn)[OT] = accb[(l + 1) & 1];
                 static_for<0, NM>([&](auto ic) {
                     constexpr int idx = decltype(ic)::value, ot = idx / SS, s2 = idx % SS, nx = idx + D;
-                    acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? afrag[l][(s2 + 1) % SS] : wr[idx % D], afrag[l][s2], acc[ot], 0, 0, 0);
+                    acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PMB(1) ? afrag[l][(s2 + 1) % SS] : wr[idx % D], afrag[l][s2], acc[ot], 0, 0, 0);
                     if constexpr (nx < NM) wr[idx % D] = frag_w<ROWB>(wimg, r, h, nx / SS, nx % SS);
                     else wr[idx % D] = frag_w<ROWB>(wnext, r, h, (nx - NM) / SS, (nx - NM) % SS);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              // a frag_w is one ds_read2_b64
@@ -732,13 +787,24 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     __builtin_amdgcn_sched_group_barrier(0x100, 4 * OT, 0);
                 }
 #pragma unroll
-                for (int s = 0; s < SS; ++s) afrag[l + 1][s] = pack8<true>(acc[s >> 1], 8 * (s & 1));
+                for (int s = 0; s < SS; ++s) afrag[l + 1][s] = PMB(8) ? raw8(acc[s >> 1], 8 * (s & 1)) : pack8<true>(acc[s >> 1], 8 * (s & 1));
             }
         }
         // ---------------- backward
         bf16x8 dfrag[SS];
         {
             f32x16 dl[OT];
+            if constexpr (SMALLIO) {
+                // (unconditional -- past the end the current pixel again: behind a branch the waits for gy below would also wait for these)
+                locate(sup + gridDim.x < nsuper ? sup + gridDim.x : sup, okn, bn_, pn_);
+                raw4(x + (size_t)bn_ * cin0 * P + pn_, cin0, xr);
+#pragma unroll
+                for (int t = 0; t < OT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dl[t][i] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dl[0][i] = (ok && h == 0 && i < coutL) ? gr[i] : 0.f;
+            } else
             load_acc<OT, SMALLIO>(gy + (size_t)b * coutL * P + p, (size_t)P, coutL, ok, h, dl);
 #pragma unroll
             for (int s = 0; s < SS; ++s) dfrag[s] = pack8<false>(dl[s >> 1], 8 * (s & 1));
@@ -765,10 +831,10 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 static_for<0, NM>([&](auto ic) {
                     constexpr int idx = decltype(ic)::value, it = kBwdAlt ? idx % OT : idx / SS, s2 = kBwdAlt ? idx / OT : idx % SS, nx = idx + D;
                     constexpr int nit = kBwdAlt ? nx % OT : (nx % NM) / SS, ns2 = kBwdAlt ? (nx % NM) / OT : nx % SS;
-                    nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NNS_PMB_EXP == 1 ? dfrag[(s2 + 1) % SS] : tr[idx % D], dfrag[s2], nd[it], 0, 0, 0);
+                    nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PMB(1) ? dfrag[(s2 + 1) % SS] : tr[idx % D], dfrag[s2], nd[it], 0, 0, 0);
                     tr[idx % D] = frag_t<ROWB>(nx < NM ? wimg : wprev, lane, ns2, 32 * nit);
                     constexpr int per = 4 * SS / NM;                                                // 8-byte image stores per MFMA
-                    if (NNS_PMB_EXP != 6) {
+                    if (!PMB(6)) {
 #pragma unroll
                         for (int j = 0; j < per; ++j) {
                             const int k = idx * per + j, s = k >> 2;
@@ -778,14 +844,14 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                         }
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    if (NNS_PMB_EXP != 6) __builtin_amdgcn_sched_group_barrier(0x200, per, 0);
+                    if (!PMB(6)) __builtin_amdgcn_sched_group_barrier(0x200, per, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                if (NNS_PMB_EXP != 2) __syncthreads();                          // layer l's images are written: over to the gradient waves
+                if (!PMB(2)) __syncthreads();                          // layer l's images are written: over to the gradient waves
                 if (l > 0) {
 #pragma unroll
-                    for (int s = 0; s < SS; ++s) dfrag[s] = NNS_PMB_EXP == 7 ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
+                    for (int s = 0; s < SS; ++s) dfrag[s] = PMB(9) ? raw8(nd[s >> 1], 8 * (s & 1)) : PMB(7) ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
                 } else if (ok) {
                     store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
@@ -796,6 +862,275 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
         // no barrier between super-tiles, the chain waves run ahead into the next forward recompute.  Odd nl: both layers share a set.
         if (nl & 1) __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The split backward with a TWO-TILE chain (round 3).  Probes of pixel_mlp_bwd_split_kernel (tools/README.md, NNS_PMB_EXP): its chain
+// waves alone take 0.90 of the kernel's 1.17 ms, and of those only 0.24 are their MFMAs -- a chain wave's conversions, image stores,
+// fragment reads and barrier all sit BETWEEN the dependent MFMA groups of its one 32-pixel tile, and the second wave of the SIMD (a
+// gradient wave) has only 8 MFMAs per layer to put into the gaps.  Here a chain wave still owns 32 pixels but as TWO 16-pixel tiles
+// (v_mfma_f32_16x16x32_bf16: same registers, same MFMA cycles per pixel) half a layer out of phase: while the MFMAs of one tile's layer
+// run, the other tile's accumulators are converted, masked and stored -- the overlap is in ONE wave's instruction stream, pinned with
+// sched_group_barrier as in pixel_mlp_fwd_pipe4_kernel.  Lane (c, g) = (lane & 15, lane >> 4): pixel c of each tile; K slot 8 g + j of
+// k-step ks is channel 32 ks + 16 (j >> 2) + 4 g + (j & 3), which is exactly what two 16-channel accumulator blocks hand the lane
+// (block 2 ks + (j >> 2), register j & 3) -- the conversion needs no cross-lane step, and the weight operands read the plain [out][in]
+// images with that K order (two 8-byte pieces 32 bytes apart; transposed: ds_read_b64_tr_b16 of rows 4 g .. 4 g + 3 and + 16).
+// Gradient waves, images, barriers and the workspace layout are those of pixel_mlp_bwd_split_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+// forward A operand: rows 16 ob + c of the plain [out][in] image, k-step ks
+template <int ROWB>
+__device__ __forceinline__ bf16x8 frag_w16(const unsigned char* wimg, int c, int g, int ob, int ks) {
+    const unsigned char* a = wimg + (16 * ob + c) * ROWB + (32 * ks + 4 * g) * 2;
+    return join8(*reinterpret_cast<const bf16x4*>(a), *reinterpret_cast<const bf16x4*>(a + 32));
+}
+// backward A operand: row = input channel 16 ib + c, K = output channels of k-step ks (transposing read; EXEC must be all ones)
+template <int ROWB>
+__device__ __forceinline__ bf16x8 frag_t16(const unsigned char* img, int lane, int ib, int ks) {
+    const int gl = lane & 15, q = gl >> 2, pp = gl & 3, g = lane >> 4;
+    const unsigned char* a0 = img + (32 * ks + 4 * g + q) * ROWB + (16 * ib + 4 * pp) * 2;
+    using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 16 * ROWB)));
+}
+// the K slots of one pixel from a [channel][pixel] global field (x or gy), rounded to bf16
+template <int KS, bool SMALL>
+__device__ __forceinline__ void load_frags16(const float* __restrict__ xb, size_t P, int cin, bool ok, int g, i32x4v (&f)[KS]) {
+    float v[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[ks][j] = 0.f;
+            if (SMALL && (ks > 0 || j > 3)) continue;                       // cin <= 4: channels 0..3 are slots 0..3 of k-step 0, lane group 0
+            const int ch = 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
+            const float t = xb[(size_t)(ch < cin ? ch : 0) * P];
+            v[ks][j] = (ok && ch < cin) ? t : 0.f;
+        }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        f[ks] = (i32x4v){pack2<false>(v[ks][0], v[ks][1]), pack2<false>(v[ks][2], v[ks][3]), pack2<false>(v[ks][4], v[ks][5]), pack2<false>(v[ks][6], v[ks][7])};
+}
+
+template <int OT, bool SMALLIO>
+__global__ __launch_bounds__(512) void pixel_mlp_bwd_c16_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                 const float* __restrict__ W, const float* __restrict__ Bv,
+                                                                 float* __restrict__ gx, float* __restrict__ ws,
+                                                                 long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
+    using U = BwdLds<OT>;
+    constexpr int ROWB = U::ROWB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nl = d.nlayers;
+    bwd_stage<OT>(lds, W, Bv, d);
+    const unsigned char* bias0 = lds + nl * U::W_BYTES;
+    unsigned char* img0 = lds + nl * (U::W_BYTES + U::B_BYTES);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const long nsuper = (npix_total + 127) / 128;
+    if (wave >= 4) {
+        bwd_gradient_waves<OT>(img0, wave, lane, nsuper, d, ws, nparams_w, nparams);
+        return;
+    }
+    // ================= chain waves =================
+    // Both tiles walk a layer together, k-step by k-step: position n of a layer's NP MFMAs is (k-step n / (2 OB), block (n / 2) % OB,
+    // tile n & 1), so that a weight fragment serves two consecutive MFMAs (one 1-KB LDS read per 32 matrix-pipe cycles, as with the
+    // 32x32x16 form) and an accumulator is touched every 2 OB positions.  Blocks complete during the LAST k-step only: blocks 0 .. OB/2-1
+    // (the next layer's k-step 0) are converted under the rest of that k-step, the other half -- kept in `late` so that the next layer may
+    // overwrite `acc` -- under the next layer's k-step 0, which does not need them yet.
+    constexpr int KS = OT, OB = 2 * OT, NF = OB * KS, NP = 2 * NF;         // k-steps of 32 channels, blocks of 16, fragments / MFMAs per layer
+    constexpr int HB = OB / 2;                                             // blocks per k-step of the next layer
+    constexpr int D = kBwdDepth < NF ? kBwdDepth : NF;                     // fragments in flight
+    static_assert(NF % D == 0, "ring slots must line up across layers");
+    const int c = lane & 15, g = lane >> 4;
+    const int cin0 = d.cin[0], coutL = d.cout[nl - 1];
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+#if NNS_PMB_TIMING
+    long tk[3] = {0, 0, 0}, tw[3] = {0, 0, 0}, tbody = 0, tbar = 0;
+#endif
+    for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+        int pb[2], pp[2]; bool ok[2];                                       // batch entry and pixel of this lane's two pixels
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long gp = sup * 128 + wave * 32 + 16 * t + c;
+            ok[t] = gp < npix_total;
+            const long gc = ok[t] ? gp : npix_total - 1;
+            pb[t] = (int)(gc / P); pp[t] = (int)(gc % P);
+        }
+        auto field = [&](auto* base, int t, int nch) { return base + (size_t)pb[t] * nch * P + pp[t]; };
+        // ---------------- forward: af[l][t] = input fragments of layer l, tile t
+        i32x4v af[kMaxLayers][2][KS];
+        load_frags16<KS, SMALLIO>(field(x, 0, cin0), (size_t)P, cin0, ok[0], g, af[0][0]);
+        load_frags16<KS, SMALLIO>(field(x, 1, cin0), (size_t)P, cin0, ok[1], g, af[0][1]);
+#if NNS_PMB_TIMING
+        const bool timed = sup == blockIdx.x + 3 * (long)gridDim.x;
+        if (timed) { tk[0] = clock64(); tw[0] = wall_clock64(); }
+#endif
+        f32x4v acc[2][OB];                                                 // forward accumulators, then the data chain's
+        f32x4v late[2][OB - HB];                                           // finished blocks HB .. OB-1, converted under the next layer
+        f32x4v biasv[OB];                                                  // reloaded for the next layer once k-step 0 has used it
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) biasv[ob] = *reinterpret_cast<const f32x4v*>(bias0 + (16 * ob + 4 * g) * 4);
+        bf16x8 wr[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) wr[q] = frag_w16<ROWB>(lds, c, g, q % OB, q / OB);
+        // conversion of accumulator block u of a tile -> half of fragment u >> 1 of the next layer's input
+        auto conv_fwd = [&](i32x4v (&dst)[KS], const f32x4v& a, int u) {
+            dst[u >> 1][2 * (u & 1)] = pack2<true>(a[0], a[1]);
+            dst[u >> 1][2 * (u & 1) + 1] = pack2<true>(a[2], a[3]);
+        };
+#pragma unroll
+        for (int l = 0; l + 1 < kMaxLayers; ++l) {
+            if (l + 1 < nl) {
+                if (PMB(5)) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) af[l + 1][t][ks] = af[l][t][ks];
+                    continue;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wimg = lds + l * U::W_BYTES;
+                const unsigned char* wnext = lds + (l + 2 < nl ? l + 1 : l) * U::W_BYTES;          // the next recomputed layer's image (clamped)
+                const unsigned char* bn = bias0 + (l + 2 < nl ? l + 1 : l) * U::B_BYTES;          // the next layer's bias (clamped)
+                static_for<0, NP>([&](auto ic) {
+                    constexpr int n = decltype(ic)::value, t = n & 1, f = n >> 1, ks = f / OB, ob = f % OB, nf = f + D;
+                    constexpr bool last = ks == KS - 1;
+                    const f32x4v cin = ks == 0 ? biasv[ob] : acc[t][ob];
+                    const f32x4v r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f % D], __builtin_bit_cast(bf16x8, af[l][t][ks]), cin, 0, 0, 0);
+                    if constexpr (last && ob >= HB) late[t][ob - HB] = r; else acc[t][ob] = r;
+                    constexpr bool cv_late = KS > 1 && ks == 0 && f < OB - HB, cv_own = KS > 1 && last && ob >= 1 && ob <= HB;
+                    if constexpr (t == 1) {
+                        wr[f % D] = frag_w16<ROWB>(nf < NF ? wimg : wnext, c, g, (nf % NF) % OB, (nf % NF) / OB);
+                        if constexpr (KS > 1 && f == OB - 1) {                                     // k-step 0 is issued: the next layer's bias
+#pragma unroll
+                            for (int o2 = 0; o2 < OB; ++o2) biasv[o2] = *reinterpret_cast<const f32x4v*>(bn + (16 * o2 + 4 * g) * 4);
+                        }
+                    }
+                    if constexpr (KS > 1) {
+                        // under k-step 0: the late blocks of the layer before (this layer's k-step 1); after block b of the last k-step: block b
+                        if constexpr (cv_late) { if (l > 0) conv_fwd(af[l][t], late[t][f], HB + f); }
+                        if constexpr (cv_own) conv_fwd(af[l + 1][t], acc[t][ob - 1], ob - 1);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (t == 1) __builtin_amdgcn_sched_group_barrier(0x100, KS > 1 && f == OB - 1 ? 1 + OB : 1, 0);
+                    if ((cv_late && l > 0) || cv_own) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                });
+                if constexpr (KS == 1) {                                                           // one k-step: nothing of the next layer can start early
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int ob = 0; ob < OB; ++ob) conv_fwd(af[l + 1][t], ob < HB ? acc[t][ob] : late[t][ob - HB], ob);
+#pragma unroll
+                    for (int o2 = 0; o2 < OB; ++o2) biasv[o2] = *reinterpret_cast<const f32x4v*>(bn + (16 * o2 + 4 * g) * 4);
+                } else if (l + 2 == nl) {                                                          // the last recomputed layer: no next k-step 0 to hide under
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int ob = HB; ob < OB; ++ob) conv_fwd(af[l + 1][t], late[t][ob - HB], ob);
+                }
+            }
+        }
+#if NNS_PMB_TIMING
+        if (timed) { tk[1] = clock64(); tw[1] = wall_clock64(); }
+#endif
+        // ---------------- backward
+        i32x4v df[2][KS];                                                  // delta_l fragments of the two tiles
+        load_frags16<KS, SMALLIO>(field(gy, 0, coutL), (size_t)P, coutL, ok[0], g, df[0]);
+        load_frags16<KS, SMALLIO>(field(gy, 1, coutL), (size_t)P, coutL, ok[1], g, df[1]);
+        bf16x8 tr[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) tr[q] = frag_t16<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, q % OB, q / OB);
+        // mask + conversion of data-chain block u -> half of fragment u >> 1 of delta, masked by the input of the layer that produced it
+        auto conv_bwd = [&](i32x4v (&dst)[KS], const f32x4v& a, const i32x4v (&act)[KS], int u) {
+            dst[u >> 1][2 * (u & 1)] = mask2(pack2<false>(a[0], a[1]), act[u >> 1][2 * (u & 1)]);
+            dst[u >> 1][2 * (u & 1) + 1] = mask2(pack2<false>(a[2], a[3]), act[u >> 1][2 * (u & 1) + 1]);
+        };
+#pragma unroll
+        for (int l = kMaxLayers - 1; l >= 0; --l) {
+            if (l < nl) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wimg = lds + l * U::W_BYTES;
+                const unsigned char* wprev = lds + (l > 0 ? l - 1 : 0) * U::W_BYTES;               // the next layer of the walk
+                unsigned char* rowD = img0 + (l & 1) * 2 * U::IMG_BYTES + (32 * wave + c) * ROWB + 8 * g;
+                // top: no layer above whose late blocks are still to be converted (decided at run time, so both forms are compiled)
+                auto layer = [&](auto topc) {
+                    constexpr bool top = decltype(topc)::value;
+                    static_for<0, NP>([&](auto ic) {
+                        constexpr int n = decltype(ic)::value, t = n & 1, f = n >> 1, ks = f / OB, ib = f % OB, nf = f + D;
+                        constexpr bool last = ks == KS - 1;
+                        const f32x4v cin = ks == 0 ? zero4 : acc[t][ib];
+                        const f32x4v r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr[f % D], __builtin_bit_cast(bf16x8, df[t][ks]), cin, 0, 0, 0);
+                        if constexpr (last && ib >= HB && KS > 1) late[t][ib - HB] = r; else acc[t][ib] = r;
+                        if constexpr (t == 1) tr[f % D] = frag_t16<ROWB>(nf < NF ? wimg : wprev, lane, (nf % NF) % OB, (nf % NF) / OB);
+                        // image rows: 4 KS 8-byte stores per tile and layer; delta's k-step 1 pieces exist from position OB on
+                        if (!PMB(6)) {
+                            constexpr int per = (4 * KS * 2 + NP - 1) / NP;                        // stores per position
+#pragma unroll
+                            for (int j = 0; j < per; ++j) {
+                                const int k = (n >> 1) * per + j;                                  // this tile's store number
+                                if (k >= 4 * KS) continue;
+                                // order: activation pieces first (all known), then delta's k-step 0, then delta's later k-steps
+                                const int img = k < 2 * KS ? 1 : 0, kk = k % (2 * KS), fks = kk >> 1, piece = kk & 1;
+                                const i32x4v src = img ? af[l][t][fks] : df[t][fks];
+                                unsigned char* dst = rowD + img * U::IMG_BYTES + 16 * t * ROWB + (32 * fks + 16 * piece) * 2;
+                                *reinterpret_cast<int2*>(dst) = make_int2(src[2 * piece], src[2 * piece + 1]);
+                            }
+                        }
+                        constexpr bool cv_late = KS > 1 && !top && ks == 0 && f < OB - HB, cv_own = KS > 1 && last && ib >= 1 && ib <= HB;
+                        if constexpr (cv_late) conv_bwd(df[t], late[t][f], af[l + 1 < kMaxLayers ? l + 1 : l][t], HB + f);
+                        if constexpr (cv_own) { if (l > 0) conv_bwd(df[t], acc[t][ib - 1], af[l][t], ib - 1); }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (t == 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (!PMB(6)) __builtin_amdgcn_sched_group_barrier(0x200, (4 * KS * 2 + NP - 1) / NP, 0);
+                        if (cv_late || (cv_own && l > 0)) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    });
+                };
+#if NNS_PMB_TIMING
+                long tl0 = 0, tl1 = 0;
+                if (timed) tl0 = clock64();
+#endif
+                if (l + 1 < nl) layer(std::false_type{}); else layer(std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+#if NNS_PMB_TIMING
+                if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tl1 = clock64(); tbody += tl1 - tl0; }
+#endif
+                if (!PMB(2)) __syncthreads();                                                      // layer l's images are written: over to the gradient waves
+#if NNS_PMB_TIMING
+                if (timed) tbar += clock64() - tl1;
+#endif
+                if constexpr (KS == 1) {
+                    if (l > 0) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int ib = 0; ib < OB; ++ib) conv_bwd(df[t], acc[t][ib], af[l][t], ib);
+                    }
+                }
+                if (l == 0) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float* gxb = field(gx, t, cin0);
+#pragma unroll
+                        for (int ib = 0; ib < OB; ++ib)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (SMALLIO && ib > 0) continue;
+                                const int ch = 16 * ib + 4 * g + i;
+                                const float v = (KS > 1 && ib >= HB) ? late[t][ib - HB][i] : acc[t][ib][i];
+                                if (ok[t] && ch < cin0) gxb[(size_t)ch * P] = v;
+                            }
+                    }
+                }
+            }
+        }
+        if (nl & 1) __syncthreads();                                                               // as in pixel_mlp_bwd_split_kernel
+#if NNS_PMB_TIMING
+        if (timed) { tk[2] = clock64(); tw[2] = wall_clock64(); }
+#endif
+    }
+#if NNS_PMB_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("c16 timing: forward %ld clk (%ld x10ns), backward %ld clk (%ld x10ns): layer bodies %ld, barriers %ld\n", (long)(tk[1] - tk[0]), (long)(tw[1] - tw[0]), (long)(tk[2] - tk[1]), (long)(tw[2] - tw[1]), tbody, tbar);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1016,6 +1351,14 @@ int launch_bwd_uniform(const float* x, const float* gy, const float* weights, co
     if (NNS_PM_SPLIT && BwdLds<OT>::total(d.nlayers) == lds && NNS_PM_IMGSETS == 2) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_split_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+#ifndef NNS_PMB_C16
+#define NNS_PMB_C16 0              // 1: two-tile chain (pixel_mlp_bwd_c16_kernel), 0: one-tile chain (pixel_mlp_bwd_split_kernel)
+#endif
+        if (NNS_PMB_C16) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_c16_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+            hipLaunchKernelGGL((pixel_mlp_bwd_c16_kernel<OT, SMALLIO>), dim3(blocks), dim3(512), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
+        } else
         hipLaunchKernelGGL((pixel_mlp_bwd_split_kernel<OT, SMALLIO>), dim3(blocks), dim3(512), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
     } else
     hipLaunchKernelGGL((pixel_mlp_bwd_uniform_kernel<OT, SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
