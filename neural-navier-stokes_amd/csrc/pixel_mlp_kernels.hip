@@ -648,24 +648,32 @@ __device__ __forceinline__ void bwd_gradient_waves(unsigned char* img0, int wave
                 // the operand fragments of k-step kk + GD are requested before the MFMA of k-step kk (round 3: an LDS read takes longer than
                 // one MFMA, so one step ahead still left every MFMA waiting)
                 constexpr int GD = KS < kBwdDepth ? KS : kBwdDepth;
-                bf16x8 fa_r[GD], fb_r[GD];
+                // (two forms behind a wave-uniform branch: written as a condition inside the loop the bias sums were computed by every wave and
+                // selected away; four partial sums: one accumulator made the 32 dot products of a layer a dependent chain)
+                auto contract = [&](auto gbc) {
+                    constexpr bool with_gb = decltype(gbc)::value;
+                    bf16x8 fa_r[GD], fb_r[GD];
+                    float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<ROWB>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<ROWB>(imgA, lane, ks0 + q, 32 * bi); }
+                    for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<ROWB>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<ROWB>(imgA, lane, ks0 + q, 32 * bi); }
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
-                    const bf16x8 fa = fa_r[kk % GD], fb = fb_r[kk % GD];
-                    if (!PMB(3)) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
-                    if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<ROWB>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<ROWB>(imgA, lane, ks0 + kk + GD, 32 * bi); }
-                    if (kk & 1) __builtin_amdgcn_sched_barrier(0);
-                    if (do_gb) {
-                        const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
+                    for (int kk = 0; kk < KS; ++kk) {
+                        const bf16x8 fa = fa_r[kk % GD], fb = fb_r[kk % GD];
+                        if (!PMB(3)) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
+                        if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<ROWB>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<ROWB>(imgA, lane, ks0 + kk + GD, 32 * bi); }
+                        if (kk & 1) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (with_gb) {
+                            const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-                        for (int j = 0; j < 8; j += 2) {
-                            const unsigned pr = (unsigned)(unsigned short)fa[j] | ((unsigned)(unsigned short)fa[j + 1] << 16);
-                            gbp[l] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pr), ones, gbp[l], false);
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned pr = (unsigned)(unsigned short)fa[2 * j] | ((unsigned)(unsigned short)fa[2 * j + 1] << 16);
+                                part[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, pr), ones, part[j], false);
+                            }
                         }
                     }
-                }
+                    if constexpr (with_gb) gbp[l] += (part[0] + part[1]) + (part[2] + part[3]);
+                };
+                if (do_gb) contract(std::true_type{}); else contract(std::false_type{});
             }
         }
         if (nl & 1) __syncthreads();                                        // end of the super-tile: see the chain waves
@@ -848,11 +856,14 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                if (!PMB(2)) __syncthreads();                          // layer l's images are written: over to the gradient waves
+                // the mask / convert step does not need the barrier: it runs while the image stores drain and the other waves arrive
                 if (l > 0) {
 #pragma unroll
                     for (int s = 0; s < SS; ++s) dfrag[s] = PMB(9) ? raw8(nd[s >> 1], 8 * (s & 1)) : PMB(7) ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
-                } else if (ok) {
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!PMB(2)) __syncthreads();                          // layer l's images are written: over to the gradient waves
+                if (l == 0 && ok) {
                     store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
             }
