@@ -170,27 +170,34 @@ __global__ __launch_bounds__(NT) void ode_mlp_fwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // forward, ONE ROW PER WORKGROUP (round 2).  The integration is Nt dependent steps of 4 (RK4) dependent MLP evaluations; the tile
 // kernel above spends 14 us per RK4 step on a 16-row MFMA tile however few of its rows are real -- and PDEFunc integrates ONE shared
-// trajectory (spectral_ode.py:69).  Here a workgroup of two waves owns one batch row and keeps ALL THREE weight matrices in
-// registers (thread n holds row n of W0 and W1: 32 + 128 values, and a 32-value slice of W2): every layer is a broadcast read of the
-// activation vector from LDS + an FMA chain per thread, 4 small barriers per evaluation -- about 2.6 us per RK4 step, and batch rows
-// run on different CUs.  Plain float32 FMAs (the sum order differs from the MFMA tile's; both are float32 dot products).
+// trajectory (spectral_ode.py:69).  Here ONE workgroup owns one batch row and keeps ALL THREE weight matrices in registers: every
+// layer is a broadcast read of the activation vector from LDS + an FMA chain per thread, 4 small barriers per evaluation, and batch
+// rows run on different CUs.  Plain float32 FMAs (the sum order differs from the MFMA tile's; both are float32 dot products).
 // ------------------------------------------------------------------------------------------
-constexpr int RT = 128;            // threads per row workgroup
+#ifndef NNS_ROW_TIMING
+#define NNS_ROW_TIMING 0             // 1: the row kernel prints the cycles of one evaluation's four phases (s_memtime)
+#endif
+constexpr int RT = 256;            // threads per row workgroup: one wave per SIMD
+// Round 3: four waves instead of two.  With 128 threads a thread carried a whole row of W1 -- 128 dependent-issue FMAs per evaluation on
+// a SIMD that issues one vector instruction every ~5 cycles to a lone wave: ~3000 cycles per evaluation, 530 us per 100 RK4 steps.  Now
+// thread (n, half) holds HALF a row (layer 1: 16 of 32 inputs, layer 2: 64 of 128), the two halves sit in lanes l and l + 32 of one wave and
+// meet in one cross-lane add; layer 3 splits its 128 inputs over eight 32-thread groups.
 __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __restrict__ z0, const float* __restrict__ W0, const float* __restrict__ b0,
                                                              const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2,
                                                              float* __restrict__ out, int mb, int K, int Nt, int method) {
-    __shared__ __attribute__((aligned(16))) float S[KP], h1[H], h2[H], part[4][KP], sb0[H], sb1[H], sb2[KP];
+    __shared__ __attribute__((aligned(16))) float S[KP], h1[H], h2[H], part[8][KP], sb2[KP];
     const int t = threadIdx.x, row = blockIdx.x;
-    const int n3 = t & 31, pq = t >> 5;                       // layer 3: output n3, quarter pq of the 128 hidden inputs
-    float w0[KP], w1[H], w2[32];
+    const int n = (t & 31) + 32 * (t >> 6), half = (t >> 5) & 1;   // layers 1, 2: output n, input half
+    const int n3 = t & 31, pq = t >> 5;                           // layer 3: output n3, inputs 16 pq .. 16 pq + 15
+    float w0[KP / 2], w1[H / 2], w2[16];
 #pragma unroll
-    for (int j = 0; j < KP; ++j) w0[j] = j < K ? W0[(size_t)t * K + j] : 0.f;
+    for (int j = 0; j < KP / 2; ++j) { const int jj = KP / 2 * half + j; w0[j] = jj < K ? W0[(size_t)n * K + jj] : 0.f; }
 #pragma unroll
-    for (int j = 0; j < H; ++j) w1[j] = W1[(size_t)t * H + j];
+    for (int j = 0; j < H / 2; ++j) w1[j] = W1[(size_t)n * H + H / 2 * half + j];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) w2[j] = n3 < K ? W2[(size_t)n3 * H + 32 * pq + j] : 0.f;
-    sb0[t] = b0[t]; sb1[t] = b1[t];
+    for (int j = 0; j < 16; ++j) w2[j] = n3 < K ? W2[(size_t)n3 * H + 16 * pq + j] : 0.f;
+    const float bias0 = half == 0 ? b0[n] : 0.f, bias1 = half == 0 ? b1[n] : 0.f;
     if (t < KP) sb2[t] = t < K ? b2[t] : 0.f;
     float y = 0.f, acc = 0.f;                                  // RK state of coefficient t (threads t < KP)
     if (t < KP) { y = t < K ? z0[(size_t)row * K + t] : 0.f; S[t] = y; }
@@ -198,47 +205,89 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
     const float dt = 1.f / (float)Nt;
     const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
     const int nstage = method == METHOD_RK4 ? 4 : (method == METHOD_RK2 ? 2 : 1);
-    for (int n = 0; n < Nt; ++n) {
+    // the sum of a value over lanes l and l ^ 32, in both (a ds_bpermute; __builtin_amdgcn_permlane32_swap of a value with itself came out
+    // of hipcc 7.2 as v84 + v84 after the swap -- wrong -- with either operand order)
+    auto half_sum = [](float z) { return z + __shfl_xor(z, 32); };
+    // LDS-only barrier: __syncthreads() also waits for the trajectory store of the step before to be acknowledged (vmcnt(0)), ~1 us per RK step
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#if NNS_ROW_TIMING
+    long tq[5] = {0, 0, 0, 0, 0};
+#endif
+    for (int it = 0; it < Nt; ++it) {
         for (int s = 0; s < nstage; ++s) {
+#if NNS_ROW_TIMING
+            const bool timed = it == 50 && s == 1;
+            if (timed) tq[0] = clock64();
+#endif
             {   // layer 1: K -> 128, ReLU
-                float a0 = sb0[t], a1 = 0.f;
+                float a0 = bias0, a1 = 0.f;
+                const float* x = S + KP / 2 * half;
+                float4 xv[KP / 8];                                         // every read in flight before the first FMA (see layer 2)
 #pragma unroll
-                for (int j = 0; j < KP; j += 8) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(S + j), x1 = *reinterpret_cast<const float4*>(S + j + 4);
+                for (int j = 0; j < KP / 8; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < KP / 2; j += 8) {
+                    const float4 x0 = xv[j / 4], x1 = xv[j / 4 + 1];
                     a0 = fmaf(w0[j], x0.x, a0); a0 = fmaf(w0[j + 1], x0.y, a0); a0 = fmaf(w0[j + 2], x0.z, a0); a0 = fmaf(w0[j + 3], x0.w, a0);
                     a1 = fmaf(w0[j + 4], x1.x, a1); a1 = fmaf(w0[j + 5], x1.y, a1); a1 = fmaf(w0[j + 6], x1.z, a1); a1 = fmaf(w0[j + 7], x1.w, a1);
                 }
-                h1[t] = fmaxf(a0 + a1, 0.f);
+                const float z = half_sum(a0 + a1);
+                if (half == 0) h1[n] = fmaxf(z, 0.f);
             }
-            __syncthreads();
+            lds_barrier();
+#if NNS_ROW_TIMING
+            if (timed) tq[1] = clock64();
+#endif
             {   // layer 2: 128 -> 128, ELU(alpha = 1); four independent chains
-                float a[4] = {sb1[t], 0.f, 0.f, 0.f};
+                float a[4] = {bias1, 0.f, 0.f, 0.f};
+                const float* x = h1 + H / 2 * half;
+                // all sixteen broadcast reads first: left to the compiler they came two at a time, each pair waited for (lgkmcnt(1), lgkmcnt(0))
+                // -- eight exposed LDS round trips, 1200 of an evaluation's 2500 cycles (s_memtime)
+                float4 xv[H / 8];
 #pragma unroll
-                for (int j = 0; j < H; j += 16) {
+                for (int j = 0; j < H / 8; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < H / 2; j += 16) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 x = *reinterpret_cast<const float4*>(h1 + j + 4 * q);
-                        a[q] = fmaf(w1[j + 4 * q], x.x, a[q]); a[q] = fmaf(w1[j + 4 * q + 1], x.y, a[q]);
-                        a[q] = fmaf(w1[j + 4 * q + 2], x.z, a[q]); a[q] = fmaf(w1[j + 4 * q + 3], x.w, a[q]);
+                        const float4 xq = xv[j / 4 + q];
+                        a[q] = fmaf(w1[j + 4 * q], xq.x, a[q]); a[q] = fmaf(w1[j + 4 * q + 1], xq.y, a[q]);
+                        a[q] = fmaf(w1[j + 4 * q + 2], xq.z, a[q]); a[q] = fmaf(w1[j + 4 * q + 3], xq.w, a[q]);
                     }
                 }
-                const float z = (a[0] + a[1]) + (a[2] + a[3]);
-                h2[t] = z > 0.f ? z : expm1f(z);
+                const float z = half_sum((a[0] + a[1]) + (a[2] + a[3]));
+                if (half == 0) h2[n] = z > 0.f ? z : expm1f(z);
             }
-            __syncthreads();
-            {   // layer 3: 128 -> K, a quarter of the inputs per thread
+            lds_barrier();
+#if NNS_ROW_TIMING
+            if (timed) tq[2] = clock64();
+#endif
+            {   // layer 3: 128 -> K, an eighth of the inputs per thread
                 float a0 = 0.f, a1 = 0.f;
+                const float* x = h2 + 16 * pq;
+                float4 xv[4];
 #pragma unroll
-                for (int j = 0; j < 32; j += 8) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(h2 + 32 * pq + j), x1 = *reinterpret_cast<const float4*>(h2 + 32 * pq + j + 4);
+                for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; j += 8) {
+                    const float4 x0 = xv[j / 4], x1 = xv[j / 4 + 1];
                     a0 = fmaf(w2[j], x0.x, a0); a0 = fmaf(w2[j + 1], x0.y, a0); a0 = fmaf(w2[j + 2], x0.z, a0); a0 = fmaf(w2[j + 3], x0.w, a0);
                     a1 = fmaf(w2[j + 4], x1.x, a1); a1 = fmaf(w2[j + 5], x1.y, a1); a1 = fmaf(w2[j + 6], x1.z, a1); a1 = fmaf(w2[j + 7], x1.w, a1);
                 }
                 part[pq][n3] = a0 + a1;
             }
-            __syncthreads();
+            lds_barrier();
+#if NNS_ROW_TIMING
+            if (timed) tq[3] = clock64();
+#endif
             if (t < KP) {   // F, then the scheme's update of this coefficient (scheme.py:21-42), as in ode_mlp_fwd_kernel
-                const float F = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) + sb2[t];
+                float pv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pv[q] = part[q][t];
+                const float F = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) + sb2[t];
                 const float k = dt * F;
                 if (method == METHOD_EULER) { acc = y + k; }
                 else if (method == METHOD_RK2) { if (s == 0) S[t] = y + 0.5f * k; else acc = y + k; }
@@ -250,12 +299,18 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
                 }
                 if (s == nstage - 1) {
                     y = acc; S[t] = y;
-                    if (t < K) out[((size_t)n * mb + row) * K + t] = y;
+                    if (t < K) out[((size_t)it * mb + row) * K + t] = y;
                 }
             }
-            __syncthreads();
+            lds_barrier();
+#if NNS_ROW_TIMING
+            if (timed) tq[4] = clock64();
+#endif
         }
     }
+#if NNS_ROW_TIMING
+    if (t == 0 && row == 0) printf("row kernel evaluation: layer1 %ld, layer2 %ld, layer3 %ld, update %ld clk\n", (long)(tq[1] - tq[0]), (long)(tq[2] - tq[1]), (long)(tq[3] - tq[2]), (long)(tq[4] - tq[3]));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1173,28 +1228,100 @@ NNS_API int nns_ode_mlp_bwd_steps_f32(const float* y, const float* W0, const flo
 }
 
 // lam[Nt-1] = g[Nt-1];  lam[s-1] = g[s-1] + lam[s] J[s]   (row vectors; J[s][b] = d y_{s+1} / d y_s of row b, [K][K])
-__global__ __launch_bounds__(64) void ode_adjoint_chain_kernel(const float* __restrict__ J, const float* __restrict__ g, float* __restrict__ lam,
-                                                               int Nt, int mb, int K) {
-    const int b = blockIdx.x, j = threadIdx.x;
-    __shared__ float cur[64];
-    float l = j < K ? g[((size_t)(Nt - 1) * mb + b) * K + j] : 0.f;
-    if (j < K) lam[((size_t)(Nt - 1) * mb + b) * K + j] = l;
-    for (int s = Nt - 1; s >= 1; --s) {
-        cur[j] = l;
+// Round 3: the first version (one wave, J read from global memory inside every step) paid an HBM / L2 round trip per step: 2.3 us x 99
+// steps for BASELINE config 2.  Now wave 0 walks the steps out of LDS (lam broadcast across the lanes, no barrier inside a chunk of steps)
+// while waves 1 .. 3 copy the NEXT chunk's Jacobians and g rows into the other half of LDS, eight wide loads in flight per thread.
+constexpr int kChainThreads = 256, kChainLoaders = kChainThreads - 64;
+constexpr int kChainLdsFloats = 18 * 1024;                  // per buffer (two buffers: 144 KiB)
+template <int KC>
+__global__ __launch_bounds__(kChainThreads) void ode_adjoint_chain_kernel(const float* __restrict__ J, const float* __restrict__ g, float* __restrict__ lam,
+                                                                          int Nt, int mb, int K, int steps_per_chunk, int vec4) {
+    extern __shared__ __attribute__((aligned(16))) float chain_lds[];
+    const int b = blockIdx.x, t = threadIdx.x, KK = K * K;
+    const int bufsz = steps_per_chunk * (KK + K);
+    // chunk c covers steps s_hi(c) = Nt - 1 - c * steps_per_chunk down to s_lo(c) >= 1
+    auto chunk_lo = [&](int s_hi) { return s_hi - steps_per_chunk + 1 > 1 ? s_hi - steps_per_chunk + 1 : 1; };
+    auto load_chunk = [&](int s_hi, float* buf) {            // loader threads only
+        const int tl = t - 64, s_lo = chunk_lo(s_hi), ns = s_hi - s_lo + 1;
+        float* Jl = buf; float* gl = buf + (size_t)steps_per_chunk * KK;
+        if (vec4) {
+            const int KK4 = KK / 4, total = ns * KK4;
+            for (int base = tl; base < total; base += kChainLoaders * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * kChainLoaders, ec = e < total ? e : total - 1, q = ec / KK4, r4 = ec - q * KK4;
+                    v[u] = reinterpret_cast<const float4*>(J + ((size_t)(s_lo + q) * mb + b) * KK)[r4];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * kChainLoaders;
+                    if (e < total) reinterpret_cast<float4*>(Jl)[e] = v[u];                  // q * KK4 + r4 == e
+                }
+            }
+        } else {
+            const int total = ns * KK;
+            for (int base = tl; base < total; base += kChainLoaders * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * kChainLoaders, ec = e < total ? e : total - 1, q = ec / KK, r = ec - q * KK;
+                    v[u] = J[((size_t)(s_lo + q) * mb + b) * KK + r];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * kChainLoaders;
+                    if (e < total) Jl[e] = v[u];
+                }
+            }
+        }
+        for (int e = tl; e < ns * K; e += kChainLoaders) { const int q = e / K, j = e - q * K; gl[e] = g[((size_t)(s_lo + q - 1) * mb + b) * K + j]; }
+    };
+    float l = 0.f;
+    if (t < 64) {
+        l = t < K ? g[((size_t)(Nt - 1) * mb + b) * K + t] : 0.f;
+        if (t < K) lam[((size_t)(Nt - 1) * mb + b) * K + t] = l;
+    } else if (Nt > 1) load_chunk(Nt - 1, chain_lds);
+    __syncthreads();
+    int cur = 0;
+    for (int s_hi = Nt - 1; s_hi >= 1; s_hi -= steps_per_chunk, cur ^= 1) {
+        const int s_lo = chunk_lo(s_hi), ns = s_hi - s_lo + 1;
+        if (t >= 64) {
+            if (s_lo > 1) load_chunk(s_lo - 1, chain_lds + (size_t)(cur ^ 1) * bufsz);
+        } else {
+            const float* Jl = chain_lds + (size_t)cur * bufsz; const float* gl = Jl + (size_t)steps_per_chunk * KK;
+            const int j = t < K ? t : K - 1;
+            for (int q = ns - 1; q >= 0; --q) {
+                const float* Jq = Jl + (size_t)q * KK + j;
+                float a[4] = {gl[q * K + j], 0.f, 0.f, 0.f};
+                // fully unrolled over the (padded) row count: the column's LDS reads are all in flight at once, lam[i] comes as a scalar (v_readlane)
+                float col[KC];
+#pragma unroll
+                for (int i = 0; i < KC; ++i) col[i] = Jq[(size_t)(i < K ? i : K - 1) * K];
+#pragma unroll
+                for (int i = 0; i < KC; ++i) {
+                    const float li = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), i));
+                    a[i & 3] = fmaf(i < K ? li : 0.f, col[i], a[i & 3]);
+                }
+                l = (a[0] + a[1]) + (a[2] + a[3]);
+                if (t < K) lam[((size_t)(s_lo + q - 1) * mb + b) * K + t] = l;
+            }
+        }
         __syncthreads();
-        const float* Js = J + ((size_t)s * mb + b) * K * K;
-        float acc = j < K ? g[((size_t)(s - 1) * mb + b) * K + j] : 0.f;
-        if (j < K)
-            for (int i = 0; i < K; ++i) acc = fmaf(cur[i], Js[(size_t)i * K + j], acc);
-        __syncthreads();
-        l = acc;
-        if (j < K) lam[((size_t)(s - 1) * mb + b) * K + j] = l;
     }
 }
 
 NNS_API int nns_ode_adjoint_chain_f32(const float* J, const float* g, float* lam, int Nt, int mb, int K, void* stream) {
     if (!J || !g || !lam || Nt < 1 || mb < 1 || K < 1 || K > 64) return fail(NNS_ERR_INVALID_ARG, "ode_adjoint_chain: bad args (Nt=%d mb=%d K=%d)", Nt, mb, K);
-    hipLaunchKernelGGL(ode_adjoint_chain_kernel, dim3(mb), dim3(64), 0, S(stream), J, g, lam, Nt, mb, K);
+    int spc = kChainLdsFloats / (K * K + K);
+    if (spc > Nt) spc = Nt;
+    if (spc < 1) spc = 1;
+    const int lds = 2 * spc * (K * K + K) * (int)sizeof(float);
+    const int vec4 = (K * K) % 4 == 0 && (reinterpret_cast<uintptr_t>(J) & 15) == 0;
+    auto kern = K <= 32 ? ode_adjoint_chain_kernel<32> : ode_adjoint_chain_kernel<64>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_adjoint_chain: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(mb), dim3(kChainThreads), lds, S(stream), J, g, lam, Nt, mb, K, spc, vec4);
     return check_launch("ode_adjoint_chain");
 }
 
