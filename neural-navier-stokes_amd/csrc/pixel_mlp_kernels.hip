@@ -875,275 +875,9 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The split backward with a TWO-TILE chain (round 3).  Probes of pixel_mlp_bwd_split_kernel (tools/README.md, NNS_PMB_EXP): its chain
-// waves alone take 0.90 of the kernel's 1.17 ms, and of those only 0.24 are their MFMAs -- a chain wave's conversions, image stores,
-// fragment reads and barrier all sit BETWEEN the dependent MFMA groups of its one 32-pixel tile, and the second wave of the SIMD (a
-// gradient wave) has only 8 MFMAs per layer to put into the gaps.  Here a chain wave still owns 32 pixels but as TWO 16-pixel tiles
-// (v_mfma_f32_16x16x32_bf16: same registers, same MFMA cycles per pixel) half a layer out of phase: while the MFMAs of one tile's layer
-// run, the other tile's accumulators are converted, masked and stored -- the overlap is in ONE wave's instruction stream, pinned with
-// sched_group_barrier as in pixel_mlp_fwd_pipe4_kernel.  Lane (c, g) = (lane & 15, lane >> 4): pixel c of each tile; K slot 8 g + j of
-// k-step ks is channel 32 ks + 16 (j >> 2) + 4 g + (j & 3), which is exactly what two 16-channel accumulator blocks hand the lane
-// (block 2 ks + (j >> 2), register j & 3) -- the conversion needs no cross-lane step, and the weight operands read the plain [out][in]
-// images with that K order (two 8-byte pieces 32 bytes apart; transposed: ds_read_b64_tr_b16 of rows 4 g .. 4 g + 3 and + 16).
-// Gradient waves, images, barriers and the workspace layout are those of pixel_mlp_bwd_split_kernel.
-// ------------------------------------------------------------------------------------------------------------------
-using f32x4v = __attribute__((ext_vector_type(4))) float;
-
-// forward A operand: rows 16 ob + c of the plain [out][in] image, k-step ks
-template <int ROWB>
-__device__ __forceinline__ bf16x8 frag_w16(const unsigned char* wimg, int c, int g, int ob, int ks) {
-    const unsigned char* a = wimg + (16 * ob + c) * ROWB + (32 * ks + 4 * g) * 2;
-    return join8(*reinterpret_cast<const bf16x4*>(a), *reinterpret_cast<const bf16x4*>(a + 32));
-}
-// backward A operand: row = input channel 16 ib + c, K = output channels of k-step ks (transposing read; EXEC must be all ones)
-template <int ROWB>
-__device__ __forceinline__ bf16x8 frag_t16(const unsigned char* img, int lane, int ib, int ks) {
-    const int gl = lane & 15, q = gl >> 2, pp = gl & 3, g = lane >> 4;
-    const unsigned char* a0 = img + (32 * ks + 4 * g + q) * ROWB + (16 * ib + 4 * pp) * 2;
-    using lds_v4 = __attribute__((address_space(3))) bf16x4;
-    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 16 * ROWB)));
-}
-// the K slots of one pixel from a [channel][pixel] global field (x or gy), rounded to bf16
-template <int KS, bool SMALL>
-__device__ __forceinline__ void load_frags16(const float* __restrict__ xb, size_t P, int cin, bool ok, int g, i32x4v (&f)[KS]) {
-    float v[KS][8];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[ks][j] = 0.f;
-            if (SMALL && (ks > 0 || j > 3)) continue;                       // cin <= 4: channels 0..3 are slots 0..3 of k-step 0, lane group 0
-            const int ch = 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
-            const float t = xb[(size_t)(ch < cin ? ch : 0) * P];
-            v[ks][j] = (ok && ch < cin) ? t : 0.f;
-        }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        f[ks] = (i32x4v){pack2<false>(v[ks][0], v[ks][1]), pack2<false>(v[ks][2], v[ks][3]), pack2<false>(v[ks][4], v[ks][5]), pack2<false>(v[ks][6], v[ks][7])};
-}
-
-template <int OT, bool SMALLIO>
-__global__ __launch_bounds__(512) void pixel_mlp_bwd_c16_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                                 const float* __restrict__ W, const float* __restrict__ Bv,
-                                                                 float* __restrict__ gx, float* __restrict__ ws,
-                                                                 long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
-    using U = BwdLds<OT>;
-    constexpr int ROWB = U::ROWB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int nl = d.nlayers;
-    bwd_stage<OT>(lds, W, Bv, d);
-    const unsigned char* bias0 = lds + nl * U::W_BYTES;
-    unsigned char* img0 = lds + nl * (U::W_BYTES + U::B_BYTES);
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const long nsuper = (npix_total + 127) / 128;
-    if (wave >= 4) {
-        bwd_gradient_waves<OT>(img0, wave, lane, nsuper, d, ws, nparams_w, nparams);
-        return;
-    }
-    // ================= chain waves =================
-    // Both tiles walk a layer together, k-step by k-step: position n of a layer's NP MFMAs is (k-step n / (2 OB), block (n / 2) % OB,
-    // tile n & 1), so that a weight fragment serves two consecutive MFMAs (one 1-KB LDS read per 32 matrix-pipe cycles, as with the
-    // 32x32x16 form) and an accumulator is touched every 2 OB positions.  Blocks complete during the LAST k-step only: blocks 0 .. OB/2-1
-    // (the next layer's k-step 0) are converted under the rest of that k-step, the other half -- kept in `late` so that the next layer may
-    // overwrite `acc` -- under the next layer's k-step 0, which does not need them yet.
-    constexpr int KS = OT, OB = 2 * OT, NF = OB * KS, NP = 2 * NF;         // k-steps of 32 channels, blocks of 16, fragments / MFMAs per layer
-    constexpr int HB = OB / 2;                                             // blocks per k-step of the next layer
-    constexpr int D = kBwdDepth < NF ? kBwdDepth : NF;                     // fragments in flight
-    static_assert(NF % D == 0, "ring slots must line up across layers");
-    const int c = lane & 15, g = lane >> 4;
-    const int cin0 = d.cin[0], coutL = d.cout[nl - 1];
-    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#if NNS_PMB_TIMING
-    long tk[3] = {0, 0, 0}, tw[3] = {0, 0, 0}, tbody = 0, tbar = 0;
-#endif
-    for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
-        int pb[2], pp[2]; bool ok[2];                                       // batch entry and pixel of this lane's two pixels
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long gp = sup * 128 + wave * 32 + 16 * t + c;
-            ok[t] = gp < npix_total;
-            const long gc = ok[t] ? gp : npix_total - 1;
-            pb[t] = (int)(gc / P); pp[t] = (int)(gc % P);
-        }
-        auto field = [&](auto* base, int t, int nch) { return base + (size_t)pb[t] * nch * P + pp[t]; };
-        // ---------------- forward: af[l][t] = input fragments of layer l, tile t
-        i32x4v af[kMaxLayers][2][KS];
-        load_frags16<KS, SMALLIO>(field(x, 0, cin0), (size_t)P, cin0, ok[0], g, af[0][0]);
-        load_frags16<KS, SMALLIO>(field(x, 1, cin0), (size_t)P, cin0, ok[1], g, af[0][1]);
-#if NNS_PMB_TIMING
-        const bool timed = sup == blockIdx.x + 3 * (long)gridDim.x;
-        if (timed) { tk[0] = clock64(); tw[0] = wall_clock64(); }
-#endif
-        f32x4v acc[2][OB];                                                 // forward accumulators, then the data chain's
-        f32x4v late[2][OB - HB];                                           // finished blocks HB .. OB-1, converted under the next layer
-        f32x4v biasv[OB];                                                  // reloaded for the next layer once k-step 0 has used it
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) biasv[ob] = *reinterpret_cast<const f32x4v*>(bias0 + (16 * ob + 4 * g) * 4);
-        bf16x8 wr[D];
-#pragma unroll
-        for (int q = 0; q < D; ++q) wr[q] = frag_w16<ROWB>(lds, c, g, q % OB, q / OB);
-        // conversion of accumulator block u of a tile -> half of fragment u >> 1 of the next layer's input
-        auto conv_fwd = [&](i32x4v (&dst)[KS], const f32x4v& a, int u) {
-            dst[u >> 1][2 * (u & 1)] = pack2<true>(a[0], a[1]);
-            dst[u >> 1][2 * (u & 1) + 1] = pack2<true>(a[2], a[3]);
-        };
-#pragma unroll
-        for (int l = 0; l + 1 < kMaxLayers; ++l) {
-            if (l + 1 < nl) {
-                if (PMB(5)) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) af[l + 1][t][ks] = af[l][t][ks];
-                    continue;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned char* wimg = lds + l * U::W_BYTES;
-                const unsigned char* wnext = lds + (l + 2 < nl ? l + 1 : l) * U::W_BYTES;          // the next recomputed layer's image (clamped)
-                const unsigned char* bn = bias0 + (l + 2 < nl ? l + 1 : l) * U::B_BYTES;          // the next layer's bias (clamped)
-                static_for<0, NP>([&](auto ic) {
-                    constexpr int n = decltype(ic)::value, t = n & 1, f = n >> 1, ks = f / OB, ob = f % OB, nf = f + D;
-                    constexpr bool last = ks == KS - 1;
-                    const f32x4v cin = ks == 0 ? biasv[ob] : acc[t][ob];
-                    const f32x4v r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[f % D], __builtin_bit_cast(bf16x8, af[l][t][ks]), cin, 0, 0, 0);
-                    if constexpr (last && ob >= HB) late[t][ob - HB] = r; else acc[t][ob] = r;
-                    constexpr bool cv_late = KS > 1 && ks == 0 && f < OB - HB, cv_own = KS > 1 && last && ob >= 1 && ob <= HB;
-                    if constexpr (t == 1) {
-                        wr[f % D] = frag_w16<ROWB>(nf < NF ? wimg : wnext, c, g, (nf % NF) % OB, (nf % NF) / OB);
-                        if constexpr (KS > 1 && f == OB - 1) {                                     // k-step 0 is issued: the next layer's bias
-#pragma unroll
-                            for (int o2 = 0; o2 < OB; ++o2) biasv[o2] = *reinterpret_cast<const f32x4v*>(bn + (16 * o2 + 4 * g) * 4);
-                        }
-                    }
-                    if constexpr (KS > 1) {
-                        // under k-step 0: the late blocks of the layer before (this layer's k-step 1); after block b of the last k-step: block b
-                        if constexpr (cv_late) { if (l > 0) conv_fwd(af[l][t], late[t][f], HB + f); }
-                        if constexpr (cv_own) conv_fwd(af[l + 1][t], acc[t][ob - 1], ob - 1);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (t == 1) __builtin_amdgcn_sched_group_barrier(0x100, KS > 1 && f == OB - 1 ? 1 + OB : 1, 0);
-                    if ((cv_late && l > 0) || cv_own) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                });
-                if constexpr (KS == 1) {                                                           // one k-step: nothing of the next layer can start early
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int ob = 0; ob < OB; ++ob) conv_fwd(af[l + 1][t], ob < HB ? acc[t][ob] : late[t][ob - HB], ob);
-#pragma unroll
-                    for (int o2 = 0; o2 < OB; ++o2) biasv[o2] = *reinterpret_cast<const f32x4v*>(bn + (16 * o2 + 4 * g) * 4);
-                } else if (l + 2 == nl) {                                                          // the last recomputed layer: no next k-step 0 to hide under
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int ob = HB; ob < OB; ++ob) conv_fwd(af[l + 1][t], late[t][ob - HB], ob);
-                }
-            }
-        }
-#if NNS_PMB_TIMING
-        if (timed) { tk[1] = clock64(); tw[1] = wall_clock64(); }
-#endif
-        // ---------------- backward
-        i32x4v df[2][KS];                                                  // delta_l fragments of the two tiles
-        load_frags16<KS, SMALLIO>(field(gy, 0, coutL), (size_t)P, coutL, ok[0], g, df[0]);
-        load_frags16<KS, SMALLIO>(field(gy, 1, coutL), (size_t)P, coutL, ok[1], g, df[1]);
-        bf16x8 tr[D];
-#pragma unroll
-        for (int q = 0; q < D; ++q) tr[q] = frag_t16<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, q % OB, q / OB);
-        // mask + conversion of data-chain block u -> half of fragment u >> 1 of delta, masked by the input of the layer that produced it
-        auto conv_bwd = [&](i32x4v (&dst)[KS], const f32x4v& a, const i32x4v (&act)[KS], int u) {
-            dst[u >> 1][2 * (u & 1)] = mask2(pack2<false>(a[0], a[1]), act[u >> 1][2 * (u & 1)]);
-            dst[u >> 1][2 * (u & 1) + 1] = mask2(pack2<false>(a[2], a[3]), act[u >> 1][2 * (u & 1) + 1]);
-        };
-#pragma unroll
-        for (int l = kMaxLayers - 1; l >= 0; --l) {
-            if (l < nl) {
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned char* wimg = lds + l * U::W_BYTES;
-                const unsigned char* wprev = lds + (l > 0 ? l - 1 : 0) * U::W_BYTES;               // the next layer of the walk
-                unsigned char* rowD = img0 + (l & 1) * 2 * U::IMG_BYTES + (32 * wave + c) * ROWB + 8 * g;
-                // top: no layer above whose late blocks are still to be converted (decided at run time, so both forms are compiled)
-                auto layer = [&](auto topc) {
-                    constexpr bool top = decltype(topc)::value;
-                    static_for<0, NP>([&](auto ic) {
-                        constexpr int n = decltype(ic)::value, t = n & 1, f = n >> 1, ks = f / OB, ib = f % OB, nf = f + D;
-                        constexpr bool last = ks == KS - 1;
-                        const f32x4v cin = ks == 0 ? zero4 : acc[t][ib];
-                        const f32x4v r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr[f % D], __builtin_bit_cast(bf16x8, df[t][ks]), cin, 0, 0, 0);
-                        if constexpr (last && ib >= HB && KS > 1) late[t][ib - HB] = r; else acc[t][ib] = r;
-                        if constexpr (t == 1) tr[f % D] = frag_t16<ROWB>(nf < NF ? wimg : wprev, lane, (nf % NF) % OB, (nf % NF) / OB);
-                        // image rows: 4 KS 8-byte stores per tile and layer; delta's k-step 1 pieces exist from position OB on
-                        if (!PMB(6)) {
-                            constexpr int per = (4 * KS * 2 + NP - 1) / NP;                        // stores per position
-#pragma unroll
-                            for (int j = 0; j < per; ++j) {
-                                const int k = (n >> 1) * per + j;                                  // this tile's store number
-                                if (k >= 4 * KS) continue;
-                                // order: activation pieces first (all known), then delta's k-step 0, then delta's later k-steps
-                                const int img = k < 2 * KS ? 1 : 0, kk = k % (2 * KS), fks = kk >> 1, piece = kk & 1;
-                                const i32x4v src = img ? af[l][t][fks] : df[t][fks];
-                                unsigned char* dst = rowD + img * U::IMG_BYTES + 16 * t * ROWB + (32 * fks + 16 * piece) * 2;
-                                *reinterpret_cast<int2*>(dst) = make_int2(src[2 * piece], src[2 * piece + 1]);
-                            }
-                        }
-                        constexpr bool cv_late = KS > 1 && !top && ks == 0 && f < OB - HB, cv_own = KS > 1 && last && ib >= 1 && ib <= HB;
-                        if constexpr (cv_late) conv_bwd(df[t], late[t][f], af[l + 1 < kMaxLayers ? l + 1 : l][t], HB + f);
-                        if constexpr (cv_own) { if (l > 0) conv_bwd(df[t], acc[t][ib - 1], af[l][t], ib - 1); }
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (t == 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        if (!PMB(6)) __builtin_amdgcn_sched_group_barrier(0x200, (4 * KS * 2 + NP - 1) / NP, 0);
-                        if (cv_late || (cv_own && l > 0)) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    });
-                };
-#if NNS_PMB_TIMING
-                long tl0 = 0, tl1 = 0;
-                if (timed) tl0 = clock64();
-#endif
-                if (l + 1 < nl) layer(std::false_type{}); else layer(std::true_type{});
-                __builtin_amdgcn_sched_barrier(0);
-#if NNS_PMB_TIMING
-                if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tl1 = clock64(); tbody += tl1 - tl0; }
-#endif
-                if (!PMB(2)) __syncthreads();                                                      // layer l's images are written: over to the gradient waves
-#if NNS_PMB_TIMING
-                if (timed) tbar += clock64() - tl1;
-#endif
-                if constexpr (KS == 1) {
-                    if (l > 0) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int ib = 0; ib < OB; ++ib) conv_bwd(df[t], acc[t][ib], af[l][t], ib);
-                    }
-                }
-                if (l == 0) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        float* gxb = field(gx, t, cin0);
-#pragma unroll
-                        for (int ib = 0; ib < OB; ++ib)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (SMALLIO && ib > 0) continue;
-                                const int ch = 16 * ib + 4 * g + i;
-                                const float v = (KS > 1 && ib >= HB) ? late[t][ib - HB][i] : acc[t][ib][i];
-                                if (ok[t] && ch < cin0) gxb[(size_t)ch * P] = v;
-                            }
-                    }
-                }
-            }
-        }
-        if (nl & 1) __syncthreads();                                                               // as in pixel_mlp_bwd_split_kernel
-#if NNS_PMB_TIMING
-        if (timed) { tk[2] = clock64(); tw[2] = wall_clock64(); }
-#endif
-    }
-#if NNS_PMB_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("c16 timing: forward %ld clk (%ld x10ns), backward %ld clk (%ld x10ns): layer bodies %ld, barriers %ld\n", (long)(tk[1] - tk[0]), (long)(tw[1] - tw[0]), (long)(tk[2] - tk[1]), (long)(tw[2] - tw[1]), tbody, tbar);
-#endif
-}
-
+// (Round 3 also built a TWO-TILE chain on v_mfma_f32_16x16x32_bf16 -- two 16-pixel tiles per chain wave so that one tile's conversion hides
+// under the other's MFMAs, in two forms -- correct and slower, 1.47 - 1.51 against 1.01 ms: profiles/r03_ab_pixel_mlp_bwd.log, DESIGN.md 7.2;
+// the code is in the history at the commit "MLP backward: gy requested before the forward recompute ...".)
 // ------------------------------------------------------------------------------------------------------------------
 // float32-operand backward (widths <= 32: e.g. BASELINE config 2's depth-4 width-32 stack), v_mfma_f32_32x32x2_f32.
 // Same structure as the bf16 kernel with OT = 1, but nothing is rounded: the accumulator registers ARE the next
@@ -1362,14 +1096,6 @@ int launch_bwd_uniform(const float* x, const float* gy, const float* weights, co
     if (NNS_PM_SPLIT && BwdLds<OT>::total(d.nlayers) == lds && NNS_PM_IMGSETS == 2) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_split_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
-#ifndef NNS_PMB_C16
-#define NNS_PMB_C16 0              // 1: two-tile chain (pixel_mlp_bwd_c16_kernel), 0: one-tile chain (pixel_mlp_bwd_split_kernel)
-#endif
-        if (NNS_PMB_C16) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(pixel_mlp_bwd_c16_kernel<OT, SMALLIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "pixel_mlp_bwd: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
-            hipLaunchKernelGGL((pixel_mlp_bwd_c16_kernel<OT, SMALLIO>), dim3(blocks), dim3(512), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
-        } else
         hipLaunchKernelGGL((pixel_mlp_bwd_split_kernel<OT, SMALLIO>), dim3(blocks), dim3(512), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
     } else
     hipLaunchKernelGGL((pixel_mlp_bwd_uniform_kernel<OT, SMALLIO>), dim3(blocks), dim3(256), lds, s, x, gy, weights, biases, gx, ws, npix, P, d, nparams_w, nparams);
