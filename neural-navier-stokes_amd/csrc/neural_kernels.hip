@@ -35,17 +35,51 @@ enum { METHOD_EULER = 0, METHOD_RK2 = 1, METHOD_RK4 = 2 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// D[16 x 16] += A[16 x Kd] * B[Kd x 16]:  A row-major [16][lda] (LDS), B row-major [Kd][ldb] at column n0
-__device__ __forceinline__ f32x4 mma_ab(const float* A, int lda, const float* B, int ldb, int n0, int Kd, f32x4 acc, int lane) {
+// D_t[16 x 16] += A[16 x KD] * B_t[KD x 16] for NTILE adjacent column tiles t:  A row-major [16][lda] (LDS);  B row-major [KD][ldb] at column
+// n0 + 16 t, or (TRANSB) B[k][col] = Bt[n0 + 16 t + col][k] with Bt row-major.  The operands of EIGHT k-steps are requested before their MFMAs,
+// one batch ahead, and the tiles share one read of the A operand (round 3: the first version issued two ds_read_b32 and waited for them in
+// front of every MFMA -- an LDS round trip per 32-cycle MFMA: 77 us for ONE backward RK4 step of a 16-row tile, of which 11 are matrix-pipe
+// time).
+template <int KD, int NTILE, bool TRANSB>
+__device__ __forceinline__ void mma_batched(const float* A, int lda, const float* B, int ldb, int n0, f32x4 (&acc)[NTILE], int lane) {
+    constexpr int UB = 8, NB = KD / (4 * UB);
+    static_assert(KD % (4 * UB) == 0, "k depth in batches of eight k-steps");
     const int r = lane & 15, q = lane >> 4;
-    for (int k0 = 0; k0 < Kd; k0 += 4) acc = mfma4(A[r * lda + k0 + q], B[(k0 + q) * ldb + n0 + r], acc);
-    return acc;
-}
-// D[16 x 16] += A[16 x Kd] * Bt^T with Bt row-major [>= c0+16][ldb]:  B[k][col] = Bt[c0 + col][k]
-__device__ __forceinline__ f32x4 mma_abt(const float* A, int lda, const float* Bt, int ldb, int c0, int Kd, f32x4 acc, int lane) {
-    const int r = lane & 15, q = lane >> 4;
-    for (int k0 = 0; k0 < Kd; k0 += 4) acc = mfma4(A[r * lda + k0 + q], Bt[(c0 + r) * ldb + k0 + q], acc);
-    return acc;
+    float a[2][UB], b[2][NTILE][UB];
+    auto request = [&](int buf, int kb) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = kb + 4 * u + q;
+            a[buf][u] = A[r * lda + k];
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) b[buf][t][u] = TRANSB ? B[(n0 + 16 * t + r) * ldb + k] : B[k * ldb + n0 + 16 * t + r];
+        }
+    };
+    // FOUR accumulator chains per wave (k-steps dealt round-robin to NSPLIT partial sums per tile): a dependent v_mfma_f32_16x16x4_f32 issues
+    // ~64 cycles after the one it waits for, not 32 -- with two chains one MLP evaluation of a 16-row tile took 9700 cycles for 3100 of MFMA
+    // (s_memtime, NNS_BWD_TIMING)
+    constexpr int NSPLIT = 4 / NTILE;
+    f32x4 part[NTILE][NSPLIT];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        part[t][0] = acc[t];
+#pragma unroll
+        for (int sp = 1; sp < NSPLIT; ++sp) part[t][sp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    request(0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (nb + 1 < NB) request((nb + 1) & 1, 4 * UB * (nb + 1));
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) part[t][u % NSPLIT] = mfma4(a[nb & 1][u], b[nb & 1][t][u], part[t][u % NSPLIT]);
+    }
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        if constexpr (NSPLIT == 2) acc[t] = part[t][0] + part[t][1];
+        else acc[t] = (part[t][0] + part[t][1]) + (part[t][2] + part[t][3]);
+    }
 }
 // D[16 x 16] += At^T * B over the 16 batch rows: D[i][n] = sum_b At[b][i0 + i] * B[b][n0 + n]
 __device__ __forceinline__ f32x4 mma_atb(const float* At, int lda, int i0, const float* B, int ldb, int n0, f32x4 acc, int lane) {
@@ -86,33 +120,37 @@ __device__ void load_mlp(MlpLds& m, float*& lds, const float* W0, const float* b
 // F = MLP(S):  S [TB][KS] -> h1 [TB][HS] -> h2 [TB][HS] -> F [TB][KS].  Ends with a barrier.
 __device__ void mlp_eval(const MlpLds& m, const float* S, float* h1, float* h2, float* F, int wave, int lane) {
     const int c = lane & 15, r0 = 4 * (lane >> 4);
+    {                                                                       // layer 1: 8 column tiles, 2 adjacent ones per wave
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mma_batched<KP, 2, false>(S, KS, m.Wt0, HS, 32 * wave, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {                                           // layer 1: 8 column tiles, 2 per wave
-        const int n0 = 16 * (wave * 2 + t);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma_ab(S, KS, m.Wt0, HS, n0, KP, acc, lane);
-        const float bb = m.b0[n0 + c];
+        for (int t = 0; t < 2; ++t) {
+            const int n0 = 16 * (wave * 2 + t);
+            const float bb = m.b0[n0 + c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h1[(r0 + r) * HS + n0 + c] = fmaxf(acc[r] + bb, 0.f);             // ReLU
+            for (int r = 0; r < 4; ++r) h1[(r0 + r) * HS + n0 + c] = fmaxf(acc[t][r] + bb, 0.f);      // ReLU
+        }
     }
     __syncthreads();
+    {                                                                       // layer 2
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        mma_batched<H, 2, false>(h1, HS, m.Wt1, HS, 32 * wave, acc, lane);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {                                           // layer 2
-        const int n0 = 16 * (wave * 2 + t);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma_ab(h1, HS, m.Wt1, HS, n0, H, acc, lane);
-        const float bb = m.b1[n0 + c];
+        for (int t = 0; t < 2; ++t) {
+            const int n0 = 16 * (wave * 2 + t);
+            const float bb = m.b1[n0 + c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float z = acc[r] + bb; h2[(r0 + r) * HS + n0 + c] = z > 0.f ? z : expm1f(z); }   // ELU(alpha = 1)
+            for (int r = 0; r < 4; ++r) { const float z = acc[t][r] + bb; h2[(r0 + r) * HS + n0 + c] = z > 0.f ? z : expm1f(z); }   // ELU(alpha = 1)
+        }
     }
     __syncthreads();
     if (wave < KP / 16) {                                                   // layer 3: KP/16 column tiles
         const int n0 = 16 * wave;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = mma_ab(h2, HS, m.Wt2, KS, n0, H, acc, lane);
+        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        mma_batched<H, 1, false>(h2, HS, m.Wt2, KS, n0, acc, lane);
         const float bb = m.b2[n0 + c];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) F[(r0 + r) * KS + n0 + c] = acc[r] + bb;
+        for (int r = 0; r < 4; ++r) F[(r0 + r) * KS + n0 + c] = acc[0][r] + bb;
     }
     __syncthreads();
 }
@@ -174,6 +212,9 @@ __global__ __launch_bounds__(NT) void ode_mlp_fwd_kernel(const float* __restrict
 // layer is a broadcast read of the activation vector from LDS + an FMA chain per thread, 4 small barriers per evaluation, and batch
 // rows run on different CUs.  Plain float32 FMAs (the sum order differs from the MFMA tile's; both are float32 dot products).
 // ------------------------------------------------------------------------------------------
+#ifndef NNS_BWD_TIMING
+#define NNS_BWD_TIMING 0             // 1: ode_mlp_bwd_kernel prints the cycles of its phases for the last time step of workgroup 0 (s_memtime)
+#endif
 #ifndef NNS_ROW_TIMING
 #define NNS_ROW_TIMING 0             // 1: the row kernel prints the cycles of one evaluation's four phases (s_memtime)
 #endif
@@ -330,6 +371,9 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+#if NNS_BWD_TIMING
+    long tq[6] = {0, 0, 0, 0, 0, 0}; tq[0] = clock64();
+#endif
     MlpLds m;
     load_mlp(m, lds, W0, b0, W1, b1, W2, b2, K, tid);
     float* BA = carve(lds, TB * HS); float* BB = carve(lds, TB * HS); float* BC = carve(lds, TB * HS);
@@ -354,6 +398,9 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
 
     for (int e = tid; e < TB * KS; e += NT) A[e] = 0.f;
     __syncthreads();
+#if NNS_BWD_TIMING
+    tq[1] = clock64();
+#endif
 
     for (int n = Nt - 1; n >= 0; --n) {
         // adjoint of y_{n+1} += grad of output n; y_n = z0 (n == 0) or states[n-1]
@@ -365,9 +412,18 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             Y[e] = y; S[e] = y;
         }
         __syncthreads();
+#if NNS_BWD_TIMING
+        if (n == Nt - 1) tq[2] = clock64();
+#endif
         // ---- recompute the stages, saving stage inputs and activations
         for (int s = 0; s < nstage; ++s) {
+#if NNS_BWD_TIMING
+            long te0 = clock64();
+#endif
             mlp_eval(m, S, BA, BB, F, wave, lane);
+#if NNS_BWD_TIMING
+            if (n == Nt - 1 && s == 1) tq[5] = clock64() - te0;
+#endif
             float* w = ws + (size_t)s * kStageFloats;
             for (int e = tid; e < TB * KS; e += NT) w[e] = S[e];
             for (int e = tid; e < TB * HS; e += NT) { w[TB * KS + e] = BA[e]; w[TB * KS + TB * HS + e] = BB[e]; }
@@ -379,6 +435,9 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             }
             __syncthreads();
         }
+#if NNS_BWD_TIMING
+        if (n == Nt - 1) tq[3] = clock64();
+#endif
         // ---- output adjoints of the stage increments k_s
         for (int e = tid; e < TB * KS; e += NT) {
             const float a = A[e];
@@ -399,14 +458,16 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             for (int t = 0; t < 4; ++t) { const int tile = wave + 4 * t, it = tile / 2, nt = tile % 2; aW2[t] = mma_atb(BB, HS, 16 * it, GF, KS, 16 * nt, aW2[t], lane); }
             if (tid < KP) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += GF[b * KS + tid]; ab2 += sacc; }
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int k0 = 16 * (wave * 2 + t);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mma_abt(GF, KS, m.Wt2, KS, k0, KP, acc, lane);            // gh2[b][k] = sum_n GF[b][n] Wt2[k][n]
+            {
+                f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                mma_batched<KP, 2, true>(GF, KS, m.Wt2, KS, 32 * wave, acc2, lane);     // gh2[b][k] = sum_n GF[b][n] Wt2[k][n]
                 const int c = lane & 15, r0 = 4 * (lane >> 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float h = BB[(r0 + r) * HS + k0 + c]; BC[(r0 + r) * HS + k0 + c] = acc[r] * (h > 0.f ? 1.f : h + 1.f); }
+                for (int t = 0; t < 2; ++t) {
+                    const int k0 = 16 * (wave * 2 + t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float h = BB[(r0 + r) * HS + k0 + c]; BC[(r0 + r) * HS + k0 + c] = acc2[t][r] * (h > 0.f ? 1.f : h + 1.f); }
+                }
             }
             __syncthreads();
             // layer 2 backward: gWt1 += h1^T gz2 ; gb1 += colsum gz2 ; gh1 = gz2 W1 -> gz1 = gh1 * relu'(z1)   (into BB)
@@ -415,14 +476,16 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             for (int t = 0; t < 16; ++t) { const int tile = wave + 4 * t, it = tile / 8, nt = tile % 8; aW1[t] = mma_atb(BA, HS, 16 * it, BC, HS, 16 * nt, aW1[t], lane); }
             if (tid < H) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += BC[b * HS + tid]; ab1 += sacc; }
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int k0 = 16 * (wave * 2 + t);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mma_abt(BC, HS, m.Wt1, HS, k0, H, acc, lane);             // gh1[b][k] = sum_n gz2[b][n] Wt1[k][n]
+            {
+                f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                mma_batched<H, 2, true>(BC, HS, m.Wt1, HS, 32 * wave, acc2, lane);      // gh1[b][k] = sum_n gz2[b][n] Wt1[k][n]
                 const int c = lane & 15, r0 = 4 * (lane >> 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float h = BA[(r0 + r) * HS + k0 + c]; BB[(r0 + r) * HS + k0 + c] = h > 0.f ? acc[r] : 0.f; }
+                for (int t = 0; t < 2; ++t) {
+                    const int k0 = 16 * (wave * 2 + t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float h = BA[(r0 + r) * HS + k0 + c]; BB[(r0 + r) * HS + k0 + c] = h > 0.f ? acc2[t][r] : 0.f; }
+                }
             }
             __syncthreads();
             // layer 1 backward: gWt0 += S^T gz1 ; gb0 += colsum gz1 ; GS = gz1 W0
@@ -432,9 +495,9 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
             if (tid < H) { float sacc = 0.f; for (int b = 0; b < TB; ++b) sacc += BB[b * HS + tid]; ab0 += sacc; }
             }
             if (wave < KP / 16) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mma_abt(BB, HS, m.Wt0, HS, 16 * wave, H, acc, lane);      // GS[b][k] = sum_n gz1[b][n] Wt0[k][n]
-                store_tile(GS, KS, 16 * wave, acc, lane);
+                f32x4 acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+                mma_batched<H, 1, true>(BB, HS, m.Wt0, HS, 16 * wave, acc1, lane);      // GS[b][k] = sum_n gz1[b][n] Wt0[k][n]
+                store_tile(GS, KS, 16 * wave, acc1[0], lane);
             }
             __syncthreads();
             // ---- scheme bookkeeping: gy += GS; pass GS on to the previous stage's increment; next GF
@@ -453,12 +516,18 @@ __global__ __launch_bounds__(NT) void ode_mlp_bwd_kernel(const float* __restrict
         }
         for (int e = tid; e < TB * KS; e += NT) A[e] = GY[e];
         __syncthreads();
+#if NNS_BWD_TIMING
+        if (n == Nt - 1) tq[4] = clock64();
+#endif
     }
     // ---- results: grad z0, and the weight/bias gradients (atomics: several batch tiles may contribute)
     for (int e = tid; e < TB * KS; e += NT) {
         const int b = e / KS, k = e % KS;
         if (row0 + b < mb && k < K) gz0[(size_t)(row0 + b) * K + k] = A[e];
     }
+#if NNS_BWD_TIMING
+    if (blockIdx.x == 0 && tid == 0) printf("ode bwd tile: weights to LDS %ld, first loads %ld, 4 stages forward %ld, 4 stages backward %ld clk (want_pg %d); one mlp_eval %ld\n", (long)(tq[1] - tq[0]), (long)(tq[2] - tq[1]), (long)(tq[3] - tq[2]), (long)(tq[4] - tq[3]), (int)want_pg, tq[5]);
+#endif
     if (!want_pg) return;
     const int c = lane & 15, r0 = 4 * (lane >> 4);
 #pragma unroll
