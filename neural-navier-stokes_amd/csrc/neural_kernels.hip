@@ -246,9 +246,15 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
     const float dt = 1.f / (float)Nt;
     const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
     const int nstage = method == METHOD_RK4 ? 4 : (method == METHOD_RK2 ? 2 : 1);
-    // the sum of a value over lanes l and l ^ 32, in both (a ds_bpermute; __builtin_amdgcn_permlane32_swap of a value with itself came out
-    // of hipcc 7.2 as v84 + v84 after the swap -- wrong -- with either operand order)
-    auto half_sum = [](float z) { return z + __shfl_xor(z, 32); };
+    // the sum of a value over lanes l and l ^ 32, in both: v_permlane32_swap exchanges the upper half of one register with the lower half of
+    // the other, so two copies of z become (z_lo, z_lo) and (z_hi, z_hi).  Inline assembly with its own wait states: the builtin
+    // (__builtin_amdgcn_permlane32_swap of a value with itself) came out of hipcc 7.2 as `v84 + v84` after the swap.  ~8 cycles instead of
+    // the ds_bpermute round trip (~130) behind __shfl_xor.
+    auto half_sum = [](float z) {
+        float p0 = z, p1 = z;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p0), "+v"(p1));
+        return p0 + p1;
+    };
     // LDS-only barrier: __syncthreads() also waits for the trajectory store of the step before to be acknowledged (vmcnt(0)), ~1 us per RK step
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 #if NNS_ROW_TIMING
