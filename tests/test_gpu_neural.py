@@ -455,3 +455,69 @@ def test_adjoint_chain_kernel_paths(Nt, mb, K, gpu_device):
     for s in range(Nt - 1, 0, -1):
         ref[s - 1] = g[s - 1].double() + torch.einsum('bi,bij->bj', ref[s], J[s].double())
     assert rel_l2(lam.numpy(), ref.numpy()) < 1e-5        # float32 recurrence: 3.8e-6 after 300 steps that grow to 1e12
+
+
+def test_pixel_mlp_backward_exact_integers_many_supertiles(gpu_device):
+    """The exact-integer indexing check on pixel counts where a workgroup of the fused backward walks SEVERAL 128-pixel super-tiles
+    (the kernel launches at most one workgroup per CU: the small cases above give every workgroup at most one).  That is the path on which
+    the next super-tile's inputs are requested during the current one's backward walk: a wrong prefetch pairing, a ragged last super-tile
+    (pixel count not a multiple of 128) or pixels of one super-tile straddling two batch items show up as non-zero differences."""
+    from nns import ops
+    from oracle import neural as ON
+    g = torch.Generator().manual_seed(23)
+    for dims, shape in (([3, 64, 64, 3], (2, 200, 201)), ([2, 48, 3], (3, 171, 157)), ([3, 32, 32, 3], (5, 127, 113))):
+        L = len(dims) - 1
+        Ws = [((torch.rand(dims[i + 1], dims[i], generator=g) < 0.12).float() * (torch.randint(0, 2, (dims[i + 1], dims[i]), generator=g) * 2 - 1).float()) for i in range(L)]
+        bs = [torch.randint(-1, 2, (dims[i + 1],), generator=g).float() for i in range(L)]
+        x = torch.randint(-2, 3, (shape[0], dims[0]) + shape[1:], generator=g).float()
+        gy = torch.randint(-1, 2, (shape[0], dims[-1]) + shape[1:], generator=g).float()
+        assert shape[0] * shape[1] * shape[2] > 2 * 128 * 256 and (shape[0] * shape[1] * shape[2]) % 128 != 0
+        ref_gx, ref_gW, ref_gb = ON.pixel_mlp_backward([w.double() for w in Ws], [b.double() for b in bs], x.double(), gy.double())
+        h = x.double()
+        for l in range(L):
+            h = torch.einsum('oc,bcxy->boxy', Ws[l].double(), h) + bs[l].double()[None, :, None, None]
+            assert h.abs().max() <= 256, (dims, l)
+            h = torch.relu(h)
+        for l in range(L):
+            assert ref_gW[l].abs().max() < 2 ** 24 and ref_gb[l].abs().max() < 2 ** 24          # the float32 sums over all pixels stay exact
+        gx, gW, gb = ops.pixel_mlp_bwd(x.cuda(), gy.cuda(), [w.cuda() for w in Ws], [b.cuda() for b in bs])
+        assert torch.equal(gx.cpu().double(), ref_gx), dims
+        for l in range(L):
+            assert torch.equal(gW[l].cpu().double(), ref_gW[l]), (dims, l)
+            assert torch.equal(gb[l].cpu().double(), ref_gb[l]), (dims, l)
+
+
+def test_pixel_mlp_backward_config3_full_shape_properties(gpu_device):
+    """The fused bf16 backward at the shape the bench times it on (depth 8, width 64, 16 x 512^2 pixels; 128 super-tiles per workgroup)
+    through size-independent properties: determinism (bitwise), batch independence of the input gradient (item b == the item alone,
+    bitwise: a per-pixel operator), additivity of the parameter gradients over a split of the batch (float32 sums in a different order:
+    1e-5), and the input gradient of a 4096-pixel sample against the float64 oracle with the kernel's bf16 operand rounding emulated."""
+    from nns import ops
+    from nns.neural_spectral.spectral_ode import PixelMLP
+    from oracle import neural as ON
+    torch.manual_seed(5)
+    m = PixelMLP(8, 64).cuda()
+    for b in m.biases:
+        torch.nn.init.normal_(b, std=0.3)
+    Ws, bs = [w.detach() for w in m.weights], [b.detach() for b in m.biases]
+    x = torch.randn(16, 3, 512, 512, device='cuda')
+    gy = torch.randn(16, 3, 512, 512, device='cuda')
+    gx, gW, gb = ops.pixel_mlp_bwd(x, gy, Ws, bs)
+    gx2, gW2, gb2 = ops.pixel_mlp_bwd(x, gy, Ws, bs)
+    assert torch.equal(gx, gx2) and all(torch.equal(a, b) for a, b in zip(gW, gW2)) and all(torch.equal(a, b) for a, b in zip(gb, gb2))
+    assert bool(torch.isfinite(gx).all())
+    for b in (0, 7, 15):
+        g1 = ops.pixel_mlp_bwd(x[b:b + 1].contiguous(), gy[b:b + 1].contiguous(), Ws, bs)[0]
+        assert torch.equal(gx[b:b + 1], g1), b
+    parts = [ops.pixel_mlp_bwd(x[q:q + 4].contiguous(), gy[q:q + 4].contiguous(), Ws, bs) for q in range(0, 16, 4)]
+    for l in range(8):
+        sW = sum(p[1][l].double() for p in parts); sb = sum(p[2][l].double() for p in parts)
+        assert rel_l2(gW[l].cpu().numpy(), sW.cpu().numpy()) < 1e-5, l
+        assert rel_l2(gb[l].cpu().numpy(), sb.cpu().numpy()) < 1e-5, l
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+    idx = torch.randint(0, 512 * 512, (4096,), device='cuda', generator=g)
+    xs = x[11].reshape(3, -1)[:, idx].reshape(1, 3, 64, 64).contiguous()
+    gs = gy[11].reshape(3, -1)[:, idx].reshape(1, 3, 64, 64).contiguous()
+    ref_gx = ON.pixel_mlp_backward([w.cpu().double() for w in Ws], [b.cpu().double() for b in bs], xs.cpu().double(), gs.cpu().double(), bf16=True)[0]
+    got = gx[11].reshape(3, -1)[:, idx].reshape(1, 3, 64, 64)
+    assert rel_l2(got.cpu().numpy(), ref_gx.numpy()) < 1e-2
