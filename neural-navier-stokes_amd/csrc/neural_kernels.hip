@@ -244,21 +244,24 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
                                                              const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2,
                                                              float* __restrict__ out, int mb, int K, int Nt, int method) {
-    __shared__ __attribute__((aligned(16))) float S[KP], h1[H], h2[H], part[8][KP], sb2[KP];
+    __shared__ __attribute__((aligned(16))) float S[KP], h1[H], h2[H];
     const int t = threadIdx.x, row = blockIdx.x;
     const int n = (t & 31) + 32 * (t >> 6), half = (t >> 5) & 1;   // layers 1, 2: output n, input half
-    const int n3 = t & 31, pq = t >> 5;                           // layer 3: output n3, inputs 16 pq .. 16 pq + 15
+    // layer 3 + the scheme's update: output n3 = 8 wave + o3, inputs 16 g3 .. 16 g3 + 15; the eight partial sums of an output sit in eight
+    // ADJACENT lanes and meet in three DPP adds, after which all eight hold F and keep the coefficient's RK state redundantly -- no partial-sum
+    // array, no fourth barrier (round 3; s_memtime: layer 3 390 + update 430 of an evaluation's 2200 cycles before)
+    const int g3 = t & 7, n3 = 8 * (t >> 6) + ((t >> 3) & 7);
     float w0[KP / 2], w1[H / 2], w2[16];
 #pragma unroll
     for (int j = 0; j < KP / 2; ++j) { const int jj = KP / 2 * half + j; w0[j] = jj < K ? W0[(size_t)n * K + jj] : 0.f; }
 #pragma unroll
     for (int j = 0; j < H / 2; ++j) w1[j] = W1[(size_t)n * H + H / 2 * half + j];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w2[j] = n3 < K ? W2[(size_t)n3 * H + 16 * pq + j] : 0.f;
+    for (int j = 0; j < 16; ++j) w2[j] = n3 < K ? W2[(size_t)n3 * H + 16 * g3 + j] : 0.f;
     const float bias0 = half == 0 ? b0[n] : 0.f, bias1 = half == 0 ? b1[n] : 0.f;
-    if (t < KP) sb2[t] = t < K ? b2[t] : 0.f;
-    float y = 0.f, acc = 0.f;                                  // RK state of coefficient t (threads t < KP)
-    if (t < KP) { y = t < K ? z0[(size_t)row * K + t] : 0.f; S[t] = y; }
+    const float bias2 = n3 < K ? b2[n3] : 0.f;
+    float y = n3 < K ? z0[(size_t)row * K + n3] : 0.f, acc = 0.f;       // RK state of coefficient n3 (the same in the eight lanes of its group)
+    if (g3 == 0) S[n3] = y;
     __syncthreads();
     const float dt = 1.f / (float)Nt;
     const float c6 = (float)(1.0 / 6.0), c3 = (float)(1.0 / 3.0);
@@ -328,9 +331,9 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
 #if NNS_ROW_TIMING
             if (timed) tq[2] = clock64();
 #endif
-            {   // layer 3: 128 -> K, an eighth of the inputs per thread
+            {   // layer 3: 128 -> K, an eighth of the inputs per lane; then F and the scheme's update of coefficient n3 (scheme.py:21-42)
                 float a0 = 0.f, a1 = 0.f;
-                const float* x = h2 + 16 * pq;
+                const float* x = h2 + 16 * g3;
                 float4 xv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
@@ -341,29 +344,24 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
                     a0 = fmaf(w2[j], x0.x, a0); a0 = fmaf(w2[j + 1], x0.y, a0); a0 = fmaf(w2[j + 2], x0.z, a0); a0 = fmaf(w2[j + 3], x0.w, a0);
                     a1 = fmaf(w2[j + 4], x1.x, a1); a1 = fmaf(w2[j + 5], x1.y, a1); a1 = fmaf(w2[j + 6], x1.z, a1); a1 = fmaf(w2[j + 7], x1.w, a1);
                 }
-                part[pq][n3] = a0 + a1;
-            }
-            lds_barrier();
-#if NNS_ROW_TIMING
-            if (timed) tq[3] = clock64();
-#endif
-            if (t < KP) {   // F, then the scheme's update of this coefficient (scheme.py:21-42), as in ode_mlp_fwd_kernel
-                float pv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) pv[q] = part[q][t];
-                const float F = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) + sb2[t];
+                float f = a0 + a1;
+                auto dpp_add = [](float v, auto ctrl) { return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, false)); };
+                f = dpp_add(f, std::integral_constant<int, 0xB1>{});            // quad_perm [1,0,3,2]: lanes g3 ^ 1
+                f = dpp_add(f, std::integral_constant<int, 0x4E>{});            // quad_perm [2,3,0,1]: lanes g3 ^ 2
+                f = dpp_add(f, std::integral_constant<int, 0x141>{});           // row_half_mirror: a lane of the other quad of the eight (all four of it hold the same sum)
+                const float F = f + bias2;
                 const float k = dt * F;
                 if (method == METHOD_EULER) { acc = y + k; }
-                else if (method == METHOD_RK2) { if (s == 0) S[t] = y + 0.5f * k; else acc = y + k; }
+                else if (method == METHOD_RK2) { if (s == 0) { if (g3 == 0) S[n3] = y + 0.5f * k; } else acc = y + k; }
                 else {
-                    if (s == 0) { acc = y + c6 * k; S[t] = y + 0.5f * k; }
-                    else if (s == 1) { acc = acc + c3 * k; S[t] = y + 0.5f * k; }
-                    else if (s == 2) { acc = acc + c3 * k; S[t] = y + k; }
+                    if (s == 0) { acc = y + c6 * k; if (g3 == 0) S[n3] = y + 0.5f * k; }
+                    else if (s == 1) { acc = acc + c3 * k; if (g3 == 0) S[n3] = y + 0.5f * k; }
+                    else if (s == 2) { acc = acc + c3 * k; if (g3 == 0) S[n3] = y + k; }
                     else { acc = acc + c6 * k; }
                 }
                 if (s == nstage - 1) {
-                    y = acc; S[t] = y;
-                    if (t < K) out[((size_t)it * mb + row) * K + t] = y;
+                    y = acc;
+                    if (g3 == 0) { S[n3] = y; if (n3 < K) out[((size_t)it * mb + row) * K + n3] = y; }
                 }
             }
             lds_barrier();
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
         }
     }
 #if NNS_ROW_TIMING
-    if (t == 0 && row == 0) printf("row kernel evaluation: layer1 %ld, layer2 %ld, layer3 %ld, update %ld clk\n", (long)(tq[1] - tq[0]), (long)(tq[2] - tq[1]), (long)(tq[3] - tq[2]), (long)(tq[4] - tq[3]));
+    if (t == 0 && row == 0) printf("row kernel evaluation: layer1 %ld, layer2 %ld, layer3 + update %ld clk\n", (long)(tq[1] - tq[0]), (long)(tq[2] - tq[1]), (long)(tq[4] - tq[2]));
 #endif
 }
 
