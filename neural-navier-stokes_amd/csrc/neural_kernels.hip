@@ -1319,34 +1319,46 @@ NNS_API int nns_ode_mlp_bwd_steps_f32(const float* y, const float* W0, const flo
 
 // lam[Nt-1] = g[Nt-1];  lam[s-1] = g[s-1] + lam[s] J[s]   (row vectors; J[s][b] = d y_{s+1} / d y_s of row b, [K][K])
 // Round 3: the first version (one wave, J read from global memory inside every step) paid an HBM / L2 round trip per step: 2.3 us x 99
-// steps for BASELINE config 2.  Now wave 0 walks the steps out of LDS (lam broadcast across the lanes, no barrier inside a chunk of steps)
-// while waves 1 .. 3 copy the NEXT chunk's Jacobians and g rows into the other half of LDS, eight wide loads in flight per thread.
+// steps for BASELINE config 2.  Now wave 0 walks the steps out of LDS (lam broadcast across the lanes by v_readlane, no barrier inside a
+// chunk of steps) while waves 1 .. 3 copy the NEXT chunk's Jacobians and g rows into the other half of LDS, eight wide loads in flight per
+// thread.  In LDS a step's matrix has a COMPILE-TIME row stride KC (rows and columns >= K stay zero from the start), so the 32 column reads
+// of a step are one base register + immediate offsets: with the runtime stride K the per-row offsets were 32 loop-invariant scalars that the
+// compiler spilled to VGPR lanes and re-read every step (197 scalar instructions per step, 0.75 us).
 constexpr int kChainThreads = 256, kChainLoaders = kChainThreads - 64;
 constexpr int kChainLdsFloats = 18 * 1024;                  // per buffer (two buffers: 144 KiB)
 template <int KC>
 __global__ __launch_bounds__(kChainThreads) void ode_adjoint_chain_kernel(const float* __restrict__ J, const float* __restrict__ g, float* __restrict__ lam,
-                                                                          int Nt, int mb, int K, int steps_per_chunk, int vec4) {
+                                                                          int Nt, int mb, int K, int steps_per_chunk, int vec4, unsigned mK, unsigned mKK) {
     extern __shared__ __attribute__((aligned(16))) float chain_lds[];
     const int b = blockIdx.x, t = threadIdx.x, KK = K * K;
-    const int bufsz = steps_per_chunk * (KK + K);
+    constexpr int MS = KC * KC + KC;                          // floats of a step in LDS: the padded matrix, then its g row
+    const int bufsz = steps_per_chunk * MS;
+    for (int e = t; e < 2 * bufsz; e += kChainThreads) chain_lds[e] = 0.f;
+    __syncthreads();
     // chunk c covers steps s_hi(c) = Nt - 1 - c * steps_per_chunk down to s_lo(c) >= 1
     auto chunk_lo = [&](int s_hi) { return s_hi - steps_per_chunk + 1 > 1 ? s_hi - steps_per_chunk + 1 : 1; };
+    // n / d for n < 65536 as the high word of n * (2^32 / d + 1): exact (checked for every d <= 4096); the loaders' index arithmetic is on the
+    // chunk's critical path (a division is ~40 instructions, four per 16-byte load)
+    auto mdiv = [](int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; };          // m = 0 stands for d = 1
+    auto place = [&](float* buf, int q, int r, float v) { const int i = mdiv(r, mK), jj = r - i * K; buf[q * MS + i * KC + jj] = v; };
     auto load_chunk = [&](int s_hi, float* buf) {            // loader threads only
         const int tl = t - 64, s_lo = chunk_lo(s_hi), ns = s_hi - s_lo + 1;
-        float* Jl = buf; float* gl = buf + (size_t)steps_per_chunk * KK;
         if (vec4) {
             const int KK4 = KK / 4, total = ns * KK4;
             for (int base = tl; base < total; base += kChainLoaders * 8) {
                 float4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int e = base + u * kChainLoaders, ec = e < total ? e : total - 1, q = ec / KK4, r4 = ec - q * KK4;
+                    const int e = base + u * kChainLoaders, ec = e < total ? e : total - 1, q = mdiv(ec, mKK), r4 = ec - q * KK4;
                     v[u] = reinterpret_cast<const float4*>(J + ((size_t)(s_lo + q) * mb + b) * KK)[r4];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int e = base + u * kChainLoaders;
-                    if (e < total) reinterpret_cast<float4*>(Jl)[e] = v[u];                  // q * KK4 + r4 == e
+                    if (e < total) {
+                        const int q = mdiv(e, mKK), r = 4 * (e - q * KK4);
+                        place(buf, q, r, v[u].x); place(buf, q, r + 1, v[u].y); place(buf, q, r + 2, v[u].z); place(buf, q, r + 3, v[u].w);
+                    }
                 }
             }
         } else {
@@ -1355,17 +1367,17 @@ __global__ __launch_bounds__(kChainThreads) void ode_adjoint_chain_kernel(const 
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int e = base + u * kChainLoaders, ec = e < total ? e : total - 1, q = ec / KK, r = ec - q * KK;
+                    const int e = base + u * kChainLoaders, ec = e < total ? e : total - 1, q = mdiv(ec, mKK), r = ec - q * KK;
                     v[u] = J[((size_t)(s_lo + q) * mb + b) * KK + r];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int e = base + u * kChainLoaders;
-                    if (e < total) Jl[e] = v[u];
+                    if (e < total) { const int q = mdiv(e, mKK); place(buf, q, e - q * KK, v[u]); }
                 }
             }
         }
-        for (int e = tl; e < ns * K; e += kChainLoaders) { const int q = e / K, j = e - q * K; gl[e] = g[((size_t)(s_lo + q - 1) * mb + b) * K + j]; }
+        for (int e = tl; e < ns * K; e += kChainLoaders) { const int q = e / K, j = e - q * K; buf[q * MS + KC * KC + j] = g[((size_t)(s_lo + q - 1) * mb + b) * K + j]; }
     };
     float l = 0.f;
     if (t < 64) {
@@ -1379,19 +1391,18 @@ __global__ __launch_bounds__(kChainThreads) void ode_adjoint_chain_kernel(const 
         if (t >= 64) {
             if (s_lo > 1) load_chunk(s_lo - 1, chain_lds + (size_t)(cur ^ 1) * bufsz);
         } else {
-            const float* Jl = chain_lds + (size_t)cur * bufsz; const float* gl = Jl + (size_t)steps_per_chunk * KK;
-            const int j = t < K ? t : K - 1;
+            const float* buf = chain_lds + (size_t)cur * bufsz;
+            const int j = t < KC ? t : KC - 1;                 // lanes >= K read zero columns
             for (int q = ns - 1; q >= 0; --q) {
-                const float* Jq = Jl + (size_t)q * KK + j;
-                float a[4] = {gl[q * K + j], 0.f, 0.f, 0.f};
-                // fully unrolled over the (padded) row count: the column's LDS reads are all in flight at once, lam[i] comes as a scalar (v_readlane)
+                const float* Jq = buf + q * MS + j;
+                float a[4] = {Jq[KC * KC], 0.f, 0.f, 0.f};    // g[s - 1][j]
                 float col[KC];
 #pragma unroll
-                for (int i = 0; i < KC; ++i) col[i] = Jq[(size_t)(i < K ? i : K - 1) * K];
+                for (int i = 0; i < KC; ++i) col[i] = Jq[i * KC];
 #pragma unroll
                 for (int i = 0; i < KC; ++i) {
                     const float li = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), i));
-                    a[i & 3] = fmaf(i < K ? li : 0.f, col[i], a[i & 3]);
+                    a[i & 3] = fmaf(li, col[i], a[i & 3]);
                 }
                 l = (a[0] + a[1]) + (a[2] + a[3]);
                 if (t < K) lam[((size_t)(s_lo + q - 1) * mb + b) * K + t] = l;
@@ -1403,15 +1414,18 @@ __global__ __launch_bounds__(kChainThreads) void ode_adjoint_chain_kernel(const 
 
 NNS_API int nns_ode_adjoint_chain_f32(const float* J, const float* g, float* lam, int Nt, int mb, int K, void* stream) {
     if (!J || !g || !lam || Nt < 1 || mb < 1 || K < 1 || K > 64) return fail(NNS_ERR_INVALID_ARG, "ode_adjoint_chain: bad args (Nt=%d mb=%d K=%d)", Nt, mb, K);
-    int spc = kChainLdsFloats / (K * K + K);
+    const int KC = K <= 32 ? 32 : 64;
+    int spc = kChainLdsFloats / (KC * KC + KC);
     if (spc > Nt) spc = Nt;
     if (spc < 1) spc = 1;
-    const int lds = 2 * spc * (K * K + K) * (int)sizeof(float);
+    const int lds = 2 * spc * (KC * KC + KC) * (int)sizeof(float);
     const int vec4 = (K * K) % 4 == 0 && (reinterpret_cast<uintptr_t>(J) & 15) == 0;
     auto kern = K <= 32 ? ode_adjoint_chain_kernel<32> : ode_adjoint_chain_kernel<64>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "ode_adjoint_chain: hipFuncSetAttribute(%d B): %s", lds, hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(mb), dim3(kChainThreads), lds, S(stream), J, g, lam, Nt, mb, K, spc, vec4);
+    auto magic = [](unsigned d) { return d == 1 ? 0u : (unsigned)((1ull << 32) / d + 1); };
+    const unsigned mK = magic((unsigned)K), mKK = magic((unsigned)(vec4 ? K * K / 4 : K * K));
+    hipLaunchKernelGGL(kern, dim3(mb), dim3(kChainThreads), lds, S(stream), J, g, lam, Nt, mb, K, spc, vec4, mK, mKK);
     return check_launch("ode_adjoint_chain");
 }
 
