@@ -63,7 +63,10 @@ __device__ void stage_weights(const PixelMlpDesc& d, const float* __restrict__ W
 #endif
 constexpr int kFwdThreads = NNS_PM_THREADS, kFwdWaves = kFwdThreads / 64;
 
-constexpr int kGenThreads = 256, kGenWaves = 4;      // the runtime-shaped (float32) kernel
+#ifndef NNS_PM_GEN_THREADS
+#define NNS_PM_GEN_THREADS 512
+#endif
+constexpr int kGenThreads = NNS_PM_GEN_THREADS, kGenWaves = kGenThreads / 64;      // the runtime-shaped (float32) kernel: its weights fill LDS, so ONE workgroup per CU -- eight waves of it
 
 template <bool BF16>
 __global__ __launch_bounds__(kGenThreads) void pixel_mlp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ Bv,
@@ -129,36 +132,42 @@ __global__ __launch_bounds__(kGenThreads) void pixel_mlp_fwd_kernel(const float*
                 }
             }
         } else {
-        for (int l = 0; l < d.nlayers; ++l) {
-            const int cin = d.cin[l], cout = d.cout[l];
-            const int ots = (cout + 31) / 32;
+        // float32 operands (v_mfma_f32_32x32x2_f32, 64 cycles each).  Round 3: a layer is a straight run of OTS * KBS * 16 MFMAs for its
+        // compile-time tile counts (four forms, chosen per layer at run time), the two output tiles' accumulator chains ALTERNATE, and the
+        // weight operand -- one dword per lane and MFMA -- comes through a ring of eight requested ahead.  Before, every MFMA sat behind a
+        // run-time `if`, its own ds_read_b32 and an lgkmcnt(0), one accumulator chain at a time: the matrix pipe 57 % busy.
+        auto layer_f32 = [&](auto otc, auto kbc, int l) {
+            constexpr int OTS = decltype(otc)::value, KBS = decltype(kbc)::value, NST = OTS * KBS * 16, RD = 8;
             const float* bl = reinterpret_cast<const float*>(lds + d.lds_bias[l]);
+            const float* wl = reinterpret_cast<const float*>(lds + d.lds_off[l]) + lane;
             f32x16 out[2];
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                if (ot < ots) {
+            for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) out[ot][i] = bl[32 * ot + acc_row(i, h)];          // bias as the initial accumulator
-                    const int kbs = (cin + 31) / 32;
-                    const float* wl = reinterpret_cast<const float*>(lds + d.lds_off[l]);
+                for (int i = 0; i < 16; ++i) out[ot][i] = ot < OTS ? bl[32 * ot + acc_row(i, h)] : 0.f;    // bias as the initial accumulator
+            // step n: k-block n / (16 OTS), k-pair (n / OTS) % 16, output tile n % OTS; its weights: [ot][kb][i][lane]
+            auto widx = [](int n) constexpr { return (((n % OTS) * KBS + n / (16 * OTS)) * 16 + (n / OTS) % 16) * 64; };
+            float ring[RD];
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        if (kb < kbs) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i)
-                                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[((ot * kbs + kb) * 16 + i) * 64 + lane], act[kb][i], out[ot], 0, 0, 0);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) out[ot][i] = 0.f;
-                }
-            }
+            for (int q = 0; q < RD; ++q) ring[q] = wl[widx(q)];
+            static_for<0, NST>([&](auto nc) {
+                constexpr int n = decltype(nc)::value, ot = n % OTS, kb = n / (16 * OTS), i = (n / OTS) % 16;
+                out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[n % RD], act[kb][i], out[ot], 0, 0, 0);
+                if constexpr (n + RD < NST) ring[n % RD] = wl[widx(n + RD)];
+            });
             const bool relu = l + 1 < d.nlayers;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) act[t][i] = relu ? fmaxf(out[t][i], 0.f) : out[t][i];
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int l = 0; l < d.nlayers; ++l) {
+            const bool o2 = d.cout[l] > 32, k2 = d.cin[l] > 32;
+            if (o2 && k2) layer_f32(I2{}, I2{}, l);
+            else if (o2) layer_f32(I2{}, I1{}, l);
+            else if (k2) layer_f32(I1{}, I2{}, l);
+            else layer_f32(I1{}, I1{}, l);
         }
         }
         if (ok) {
@@ -1133,7 +1142,13 @@ NNS_API int nns_pixel_mlp_fwd_f32(const float* x, const float* weights, const fl
     if (!bf16 && lds > 160 * 1024) return fail(NNS_ERR_UNSUPPORTED, "pixel_mlp_fwd: weights need %d B of LDS (> 160 KiB)", lds);
     const long npix = (long)mb * P;
     const long ntiles = (npix + 31) / 32;
-    long blocks = (ntiles + kGenWaves - 1) / kGenWaves; if (blocks > 1024) blocks = 1024;
+    long blocks = (ntiles + kGenWaves - 1) / kGenWaves;
+    {   // persistent: the weights are staged once per workgroup (128 KB at depth 8, width 64: a workgroup per CU)
+        int cus = 256, dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        const long cap = (long)cus * (lds > 80 * 1024 ? 1 : 2);
+        if (blocks > cap) blocks = cap;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
     if (bf16) {
