@@ -1,0 +1,20 @@
+"""Developer helper: BASELINE config 1 (chorin_fd 64 x 64 cavity, float64, nit = 50) stepping alone (for `rocprofv3 --kernel-trace --stats`)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'neural-navier-stokes_amd')):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+from nns.chorin_fd import NavierStokesSystem
+from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+n = 64
+dx = dy = 2. / (n - 1)
+u_bc = [D(0, 'left', dx, dy), D(1, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
+v_bc = [D(0, 'left', dx, dy), D(0, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
+p_bc = [D(0, 'top', dx, dy), N(0, 'bottom', dx, dy), N(0, 'left', dx, dy), N(0, 'right', dx, dy)]
+z = np.zeros((n, n))
+s = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=200, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02, beta=1.25, method='explicit')
+s.simulate_device(use_graph=False)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+s.simulate_device(use_graph=False)
+torch.cuda.synchronize(); print('cfg1: %.3f ms per step' % ((time.perf_counter() - t0) / 200 * 1e3))
