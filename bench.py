@@ -487,6 +487,24 @@ def main():
             standalone['both_rowpass_back_to_back'] = time_kernel(rowpass, iters)
         else:
             kt = dict(standalone)
+        # this box's own streaming ceiling, measured in this run: a device-to-device copy of one 268 MB field (1 read + 1 write stream).  The pool's
+        # boxes differ by ~10 % in every HBM-bound kernel; tools/streams_bench.hip (profiles/r03_streams_bench.txt) shows a pure copy with the row
+        # pass's 8 + 6 streams within 5 % of this figure, and the row pass at 96-100 % of that copy.
+        box_copy = None
+        try:
+            src, dst = f[0], torch.empty_like(f[0])
+            for _ in range(3):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            c1.record(); torch.cuda.synchronize()
+            box_copy = 2.0 * src.numel() * src.element_size() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del dst
+        except Exception:
+            box_copy = None
         dom = max(kt, key=kt.get)
         alg_bytes = BYTES_PER_PT[dom] * pts
         achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
@@ -511,6 +529,7 @@ def main():
                                   compulsory=STEP_BYTES_COMPULSORY * pts / step_s / 1e9 / HBM_PEAK_GBS)) if fused and not slab else None
         roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, traffic_source=traffic_source, step=step_obj,
+                        box_copy_GBs=box_copy, frac_of_box_copy=(achieved / box_copy if box_copy else None),
                         algorithmic_bytes_per_launch=alg_bytes, avg_launch_ms=kt[dom],
                         all_kernels={k: dict(avg_launch_ms=v, bytes_per_pt=BYTES_PER_PT[k],
                                              achieved_GBs=BYTES_PER_PT[k] * pts / (v * 1e-3) / 1e9) for k, v in kt.items()},
