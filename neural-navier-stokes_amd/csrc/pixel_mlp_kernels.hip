@@ -578,6 +578,9 @@ constexpr int kBwdDepth = NNS_PMB_DEPTH;
 #ifndef NNS_PMB_TIMING
 #define NNS_PMB_TIMING 0           // 1: the two-tile kernel prints the cycles of one super-tile's forward and backward halves (wave 0 of workgroup 0)
 #endif
+#ifndef NNS_PMB_TIMING
+#define NNS_PMB_TIMING 0           // 1: the split backward prints the cycles of one super-tile's phases (s_memtime stamps in wave 0 of workgroup 0)
+#endif
 #ifndef NNS_PMB_PRIO
 #define NNS_PMB_PRIO 0
 #endif
@@ -746,7 +749,14 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
     // super-tile's x before the backward walk.
     bool okn = false; int bn_ = 0, pn_ = 0; float xr[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (SMALLIO) { locate(blockIdx.x, okn, bn_, pn_); raw4(x + (size_t)bn_ * cin0 * P + pn_, cin0, xr); }
+#if NNS_PMB_TIMING
+    long tk[4] = {0, 0, 0, 0}, tbody = 0, tbar = 0;
+#endif
     for (long sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+#if NNS_PMB_TIMING
+        const bool timed = sup == blockIdx.x + 3 * (long)gridDim.x;
+        if (timed) tk[0] = clock64();
+#endif
         bool ok; int b, p;
         if constexpr (SMALLIO) { ok = okn; b = bn_; p = pn_; } else locate(sup, ok, b, p);
         // ---------------- forward: afrag[l] = input fragments of layer l
@@ -807,6 +817,9 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 for (int s = 0; s < SS; ++s) afrag[l + 1][s] = PMB(8) ? raw8(acc[s >> 1], 8 * (s & 1)) : pack8<true>(acc[s >> 1], 8 * (s & 1));
             }
         }
+#if NNS_PMB_TIMING
+        if (timed) tk[1] = clock64();
+#endif
         // ---------------- backward
         bf16x8 dfrag[SS];
         {
@@ -826,12 +839,19 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #pragma unroll
             for (int s = 0; s < SS; ++s) dfrag[s] = pack8<false>(dl[s >> 1], 8 * (s & 1));
         }
+#if NNS_PMB_TIMING
+        if (timed) tk[2] = clock64();
+#endif
         bf16x8 tr[D];
 #pragma unroll
         for (int q = 0; q < D; ++q) tr[q] = frag_t<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, kBwdAlt ? q / OT : q % SS, 32 * (kBwdAlt ? q % OT : q / SS));
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
             if (l < nl) {
+#if NNS_PMB_TIMING
+                long tl0 = 0, tl1 = 0;
+                if (timed) tl0 = clock64();
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* wimg = lds + l * U::W_BYTES;
                 f32x16 nd[OT];
@@ -871,7 +891,13 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     for (int s = 0; s < SS; ++s) dfrag[s] = PMB(9) ? raw8(nd[s >> 1], 8 * (s & 1)) : PMB(7) ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if NNS_PMB_TIMING
+                if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tl1 = clock64(); tbody += tl1 - tl0; }
+#endif
                 if (!PMB(2)) __syncthreads();                          // layer l's images are written: over to the gradient waves
+#if NNS_PMB_TIMING
+                if (timed) tbar += clock64() - tl1;
+#endif
                 if (l == 0 && ok) {
                     store_acc<OT, SMALLIO>(gx + (size_t)b * cin0 * P + p, (size_t)P, cin0, h, nd);
                 }
@@ -881,7 +907,15 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
         // read from (even), and its second ones are written after a barrier the gradient waves only reach once they are done with layer 0:
         // no barrier between super-tiles, the chain waves run ahead into the next forward recompute.  Odd nl: both layers share a set.
         if (nl & 1) __syncthreads();
+#if NNS_PMB_TIMING
+        if (timed) tk[3] = clock64();
+#endif
     }
+#if NNS_PMB_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("split backward, one super-tile of wave 0 (cycles): forward recompute %ld, gy convert %ld, backward walk %ld (MFMA loops + mask / convert %ld, barrier waits %ld), whole %ld\n",
+               (long)(tk[1] - tk[0]), (long)(tk[2] - tk[1]), (long)(tk[3] - tk[2]), tbody, tbar, (long)(tk[3] - tk[0]));
+#endif
 }
 
 // (Round 3 also built a TWO-TILE chain on v_mfma_f32_16x16x32_bf16 -- two 16-pixel tiles per chain wave so that one tile's conversion hides
