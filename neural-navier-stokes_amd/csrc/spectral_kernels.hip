@@ -734,16 +734,20 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
         const int cc = mt % CW, cr = mt / CW;
         float* stage = reinterpret_cast<float*>(lines + (size_t)cc * SL::LINE_BYTES) + (cc % 8) * SL::SKEW_DW + 4 * cr;       // [field][row]
         float R[3][NR];
-        // addresses: a uniform grid base (scalar registers) + a 32-bit element offset per lane, recomputed per tile from an opaque
+        // addresses: a uniform grid base (scalar registers) + a 32-bit BYTE offset per lane, recomputed per tile from an opaque
         // seed (left alone, the compiler keeps 32 precomputed 64-bit row offsets alive across the whole loop and spills them)
         // (a lane's four consecutive rows never straddle a segment: seg_rows is a power of two >= 4, checked on the host)
+        // Round 3: BYTE offsets, so that a load is `global_load_dword v, v_off, s[base]` -- with element offsets every access carried a
+        // 64-bit shift-and-add (96 v_lshl_add_u64 + 32 v_lshlrev_b64 per tile and direction, on the SIMDs the transform waves compute on).
         auto off32 = [&](int i, unsigned seed, unsigned crv) -> unsigned {
             const unsigned r0 = 4u * crv + 4u * MROWS * (unsigned)(i >> 2);
             unsigned o;
             if constexpr (SEG) o = (r0 >> sg.shift) * (unsigned)sg.stride + (r0 & ((1u << sg.shift) - 1u)) * (unsigned)ny;
             else o = r0 * (unsigned)ny;
-            return seed + o + (unsigned)(i & 3) * (unsigned)ny;
+            return (seed + o + (unsigned)(i & 3) * (unsigned)ny) * 4u;
         };
+        auto at = [](const float* base, unsigned byte_off) -> const float& { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+        auto at_w = [](float* base, unsigned byte_off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off); };
         auto load_tile = [&](long tt) {
             int j0; size_t g;
             tile_coords(tt, j0, g);
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const unsigned c = off32(i, col, crv);
-                R[0][i] = ug[c]; R[1][i] = vg[c]; R[2][i] = pg[c];
+                R[0][i] = at(ug, c); R[1][i] = at(vg, c); R[2][i] = at(pg, c);
             }
         };
         auto store_tile = [&](long tt) {
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const unsigned c = off32(i, col, crv);
-                    ug[c] = R[0][i]; vg[c] = R[1][i]; pg[c] = R[2][i];
+                    at_w(ug, c) = R[0][i]; at_w(vg, c) = R[1][i]; at_w(pg, c) = R[2][i];
                 }
             }
         };
@@ -866,11 +870,11 @@ int launch_xpass(const float* u, const float* v, const float* p, float* ru, floa
 #ifndef NNS_XPASS_SPLIT
 #define NNS_XPASS_SPLIT 1          // 1: spec_xpass_split_kernel (8 transform waves + 4 memory waves), 0: spec_xpass_kernel
 #endif
-    // the role-split kernel's memory waves address with a scalar grid base + a 32-BIT element offset per lane: the largest offset inside
-    // one grid (SEG: across all source-rank segments) must stay below 2^32; beyond that the older kernel (size_t row offsets) takes over
+    // the role-split kernel's memory waves address with a scalar grid base + a 32-BIT BYTE offset per lane: the largest element offset inside
+    // one grid (SEG: across all source-rank segments) must stay below 2^30; beyond that the older kernel (size_t row offsets) takes over
     const unsigned long long max_off = SEG ? (unsigned long long)((N >> sg.shift) - 1) * (unsigned long long)sg.stride + ((unsigned long long)ny << sg.shift)
                                            : (unsigned long long)N * (unsigned long long)ny;
-    const bool off32_ok = max_off < (1ull << 32);
+    const bool off32_ok = max_off < (1ull << 30);
     if (NNS_XPASS_SPLIT && off32_ok) {
         auto kern = spec_xpass_split_kernel<N, TF, SEG>;
         using SL = SplitLds<N, TF>;
