@@ -10,12 +10,14 @@ n, B = 1024, 64
 f = [torch.randn(B, n, n, device='cuda') for _ in range(5)]
 L = 2 * np.pi
 out = {}
-for name, prec in (('library pick (all-float32 here)', 1), ('float64 forward', 2), ('library pick (all-float32 here) ', 1), ('float64 forward ', 2)):
-    for _ in range(3):
+PROFILE = os.environ.get('NNS_PROFILE', '0') == '1'            # under rocprofv3 (tools/prof_any.sh): the library's pick only, few launches
+cases = (('library pick (all-float32 here)', 1),) if PROFILE else (('library pick (all-float32 here)', 1), ('float64 forward', 2), ('library pick (all-float32 here) ', 1), ('float64 forward ', 2))
+for name, prec in cases:
+    for _ in range(1 if PROFILE else 3):
         ops.spec_residual_bwd(*f, 1e-3, L, L, 1.0, L / 1000, precise=prec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(4 if PROFILE else 20):
         ops.spec_residual_bwd(*f, 1e-3, L, L, 1.0, L / 1000, precise=prec)
     torch.cuda.synchronize()
-    out[name] = 1e3 * (time.perf_counter() - t0) / 20
+    out[name] = 1e3 * (time.perf_counter() - t0) / (4 if PROFILE else 20)
 print(json.dumps(dict(spec_bwd_ms=out)))
