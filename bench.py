@@ -21,8 +21,10 @@ the ranks -- nearest-neighbour halo send/recv for the stencil, two all-to-all tr
 chunks pipelined so the collectives overlap the kernels (nns/slab.py) -- "scaling": "strong", `value` = 64 x 1024^2
 points / step time (max over ranks).  The same run also reports, as `batch_sharded`, the embarrassingly parallel
 alternative (every rank its own 64 grids, no data-path collective, weak scaling), `transport` (the backend really used),
-`rccl_ranks` (a device all-reduce of ones) and `phases` (per-phase times of one un-pipelined evaluation).  If the slab
-run fails or hangs, the self-launcher re-runs the ranks with `--mode batch` and says so in `launcher`.
+`rccl_ranks` (a device all-reduce of ones) and `phases` (per-phase times of one un-pipelined evaluation).  A slab run that
+fails or hangs makes the launcher exit non-zero with the ranks' logs on stderr (the cause is to be found and fixed, not papered over);
+only with `--fallback-batch` does it re-run the ranks in `--mode batch`, and then the line says so in `launcher` and carries the
+batch number under `value` with `scaling: weak`.  Both attempts and the teardown fit 540 s (`--launch-timeout`, default 240 s each).
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- for the dominant kernel: algorithmic bytes per launch / its average launch time,
@@ -146,8 +148,9 @@ def slab_phases(sl, f, iters):
     P, nyl, c = sl.P, sl.nyloc, sl.compute
     shape = (P, 3, B, nloc, nyl)
     send, recv, back, got = (sl._buf(('ph', i), shape, u) for i in range(4))
-    parts = [torch.empty_like(u) for _ in range(3)]
+    first, last, top, bot = sl._halo_bufs(u, 3, 'ph')
     out_fd = tuple(torch.empty_like(u) for _ in range(3))
+    out_sp = tuple(torch.empty_like(u) for _ in range(3))
     acc = {}
 
     def timed(name, fn):
@@ -159,14 +162,13 @@ def slab_phases(sl, f, iters):
     for it in range(iters + 1):
         if it == 1:
             acc.clear()                                        # first round = warm-up
-        h, top, bot = timed('halo_pack_and_post', lambda: sl.start_halo([u, v, p], tag='ph'))
-        timed('transpose_pack', lambda: c.transpose_pack([u, v, p], send, P))
+        timed('pack_with_halo_rows', lambda: c.pack_halo([u, v, p], send, first, last, 0, P))
+        h = timed('halo_post', lambda: sl.tr.ring_exchange(first, last, bot, top, wrap=True))
         timed('all_to_all_1', lambda: sl.tr.all_to_all(recv, send).wait())
         timed('column_pass', lambda: c.spec_xpass_seg(recv, back, B, sl.nx, nyl, nloc, sl.Lx, sl.rho, sl.nu, sl.precise))
         timed('all_to_all_2', lambda: sl.tr.all_to_all(got, back).wait())
-        timed('transpose_unpack', lambda: c.transpose_unpack(got, parts, P))
         timed('halo_wait', lambda: h.wait())
-        timed('row_pass', lambda: c.both_rowpass_halo(u, v, p, up, vp, top, bot, parts, sl.dt, sl.dx, sl.Ly, sl.rho, sl.nu, sl.precise, out_fd=out_fd))
+        timed('row_pass_on_receive_buffer', lambda: c.both_rowpass_halo_seg(u, v, p, up, vp, top, bot, got, sl.dt, sl.dx, sl.Ly, sl.rho, sl.nu, sl.precise, out_fd, out_sp))
     return {k: v / iters for k, v in acc.items()}
 
 
@@ -185,7 +187,6 @@ def _spawn_ranks(n, argv, timeout_s, script=None):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=(r == 0)))
     import threading
@@ -219,30 +220,45 @@ def _spawn_ranks(n, argv, timeout_s, script=None):
     return rc, lines, note
 
 
+LAUNCH_TOTAL_S = 540.0           # everything the self-launcher does (all attempts + teardown) fits the driver's 600 s bench limit
+
+
 def self_launch(args, argv=None, script=None):
     """`python bench.py --gpus N` (N > 1) outside a launcher: run the N ranks as child processes and relay rank 0's JSON line.
-    The default mode is slab; if that attempt fails or hangs the ranks are started again in batch mode (fresh processes) and the
-    line says so -- a measured weak-scaling number with the slab failure on record instead of no line at all."""
-    argv = list(sys.argv[1:] if argv is None else argv)
-    modes = [args.mode] if args.mode is not None else ['slab', 'batch']
+    ONE attempt in the requested mode (default slab).  If it fails or hangs, the launcher exits NON-ZERO with the failure on stderr: a hang in
+    the multi-GPU path must surface as a failure so that its cause is found from the logs and fixed.  With `--fallback-batch` a failed
+    slab attempt is followed by a batch-mode attempt in fresh processes; the line then says so (`launcher.failed_attempts`, `scaling: weak`).
+    Time: every attempt is cut at --launch-timeout, and the attempts plus teardown at LAUNCH_TOTAL_S in all."""
+    argv = [a for a in (sys.argv[1:] if argv is None else argv) if a != '--fallback-batch']
+    modes = [args.mode or 'slab']
+    if args.fallback_batch and modes[0] == 'slab':
+        modes.append('batch')
     failures = []
-    for mode in modes:
+    t_start = time.monotonic()
+    for i, mode in enumerate(modes):
+        left = LAUNCH_TOTAL_S - (time.monotonic() - t_start) - 15.0 * (len(modes) - i)           # 15 s of teardown per attempt still to come
+        limit = min(args.launch_timeout, left)
+        if limit < 25:
+            failures.append(dict(mode=mode, status=124, note='not started: %.0f s left of the launcher\'s %.0f s' % (left, LAUNCH_TOTAL_S)))
+            break
         a = argv + ([] if args.mode is not None else ['--mode', mode])
-        log('bench: starting %d ranks (%s) as child processes ...' % (args.gpus, mode))
-        rc, lines, note = _spawn_ranks(args.gpus, a, args.launch_timeout, script)
+        log('bench: starting %d ranks (%s) as child processes, limit %.0f s ...' % (args.gpus, mode, limit))
+        rc, lines, note = _spawn_ranks(args.gpus, a, limit, script)
         js = [l for l in lines if l.startswith('{')]
         if rc == 0 and js:
             line = js[-1]
             try:
                 j = json.loads(line)
-                j['launcher'] = dict(kind='self-launched child ranks (python bench.py --gpus %d)' % args.gpus, mode=mode, failed_attempts=failures)
+                j['launcher'] = dict(kind='self-launched child ranks (python bench.py --gpus %d)' % args.gpus, mode=mode, failed_attempts=failures,
+                                     seconds=time.monotonic() - t_start)
                 line = json.dumps(j)
             except ValueError:
                 pass
             print(line, flush=True)
             return 0
         failures.append(dict(mode=mode, status=rc, note=note))
-        log('bench: the %s attempt failed (status %s%s)' % (mode, rc, ', ' + note if note else ''))
+        log('bench: the %s attempt FAILED (status %s%s)%s' % (mode, rc, ', ' + note if note else '',
+                                                               '' if i + 1 < len(modes) else ' -- no line; see the ranks\' output above'))
     return failures[-1]['status'] or 1
 
 
@@ -267,11 +283,13 @@ def main():
                     help="N > 1 only.  slab (default): the SAME --batch grids are slab-decomposed by rows over the ranks -- halo "
                          "send/recv for the stencil, 2 all-to-alls per spectral evaluation (strong scaling); "
                          "batch: every rank owns --batch whole grids, no data-path collective (weak scaling)")
-    ap.add_argument('--chunks', type=int, default=None, help='slab mode: batch chunks pipelined through the stages (default: 2 on RCCL, 1 on gloo)')
+    ap.add_argument('--chunks', type=int, default=None, help='slab mode: batch chunks pipelined through the stages (default 1; the chunked pipeline is also timed as an extra, `pipelined`)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` object (BASELINE configs 1, 2, 3, 5; ~20 s, N = 1 only)')
     ap.add_argument('--loopback', action='store_true', help='rehearsal on ONE GPU: --gpus 1 --mode slab --loopback runs the slab path with every message going '
                     'through a world-1 RCCL process group to the rank itself (device buffers, async collectives; not a scaling number)')
-    ap.add_argument('--launch-timeout', type=float, default=420.0, help='self-launcher: seconds before the child ranks are killed')
+    ap.add_argument('--launch-timeout', type=float, default=240.0, help='self-launcher: seconds before the child ranks of ONE attempt are killed (all attempts + teardown: 540 s)')
+    ap.add_argument('--fallback-batch', action='store_true', help='self-launcher: after a failed / hung slab attempt, run the ranks again in --mode batch (off by default: a slab failure exits non-zero)')
+    ap.add_argument('--extras-timeout', type=float, default=150.0, help='N > 1: seconds the untimed extras after the headline (phases, chunked pipeline, batch splits) may take before the line is printed without them')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -281,6 +299,9 @@ def main():
     if args.loopback and (args.gpus != 1 or args.backend != 'nccl'):
         raise SystemExit('--loopback is the one-GPU RCCL rehearsal: --gpus 1 --backend nccl')
 
+    # RCCL peer-to-peer IPC on this pool needs the dmabuf mode (the host driver supports no legacy IPC handles: hipIpcGetMemHandle fails without
+    # it); set here, before the first HIP call, so that self-launched children and torch.distributed.run ranks run in the SAME HSA mode
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -356,12 +377,35 @@ def main():
     # N > 1 extras, measured after the timed region: what RCCL really saw, one un-pipelined evaluation phase by phase, and the
     # embarrassingly parallel alternative (every rank its own --batch grids)
     multi = None
+    pts = float(B) * n * n
+    value = (1 if slab else world) * pts * args.steps / elapsed          # slab: the ranks share ONE batch of grids
+    watchdog = None
     if world > 1 or args.loopback:
+        # The headline is measured.  What follows (phase timings, the chunked pipeline, the batch splits) are untimed EXTRAS over collectives that
+        # no multi-GPU box has run before the driver's: if they do not finish within --extras-timeout, rank 0 prints the line with what it has and
+        # every rank leaves (os._exit: a rank stuck inside a collective cannot be joined).
+        import threading
+        partial = dict(metric='grid-point residual-updates/sec at 1024^2 (FD 5-point + spectral residual on the same inputs)', value=value,
+                       unit='residual-updates/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+                       higher_is_better=True, scaling='strong' if slab else 'weak', vs_baseline=None, dtype='f32', data='synthetic',
+                       config=dict(workload='periodic-box NS residual, %dx%d, batch %d, FD %d-point + Fourier spectral' % (n, n, B, args.stencil),
+                                   parallelism=('row-slab x%d' % world) if slab else 'batch-sharded x%d' % world),
+                       roofline=None, cpu_baseline=None)
+
+        def bail():
+            if rank == 0:
+                partial['extras'] = 'NOT COMPLETED within %.0f s: the line carries the timed headline only' % args.extras_timeout
+                print(json.dumps(partial), flush=True)
+            log('bench: rank %d: extras exceeded %.0f s -- leaving' % (rank, args.extras_timeout))
+            os._exit(0 if rank == 0 else 3)
+        watchdog = threading.Timer(args.extras_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
         ones = torch.ones(1, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(ones)
         multi = dict(transport=dict(backend=dist.get_backend(), library='RCCL (torch "nccl" on ROCm)' if args.backend == 'nccl' else
                                     'gloo: device buffers staged through the host, every collective blocking (rehearsal only)',
-                                    device_buffers=args.backend == 'nccl'),
+                                    device_buffers=args.backend == 'nccl', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')),
                      rccl_ranks=int(ones.item()) if args.backend == 'nccl' else 0, ranks_confirmed_by_all_reduce=int(ones.item()))
         if slab:
             # how long the HOST takes to enqueue one step (the per-chunk pipeline is ~10 launches / collectives per chunk from Python): if this
@@ -373,6 +417,26 @@ def main():
             host_ms = 1e3 * (time.perf_counter() - th0) / 10
             torch.cuda.synchronize()
             multi['host_enqueue_ms_per_step'] = host_ms
+            # the batch-chunk pipeline (collectives of chunk c+1 under the kernels of chunk c), timed like the headline: an extra until a multi-GPU
+            # run has confirmed the interleaving (the headline runs --chunks, default 1)
+            if sl._nchunks(B) == 1 and B >= 2:
+                for _ in range(min(args.warmup, 5)):
+                    sl.both(*f, stencil=args.stencil, chunks=2)
+                sync_all()
+                tp0 = time.perf_counter()
+                for _ in range(args.steps):
+                    sl.both(*f, stencil=args.stencil, chunks=2)
+                sync_all()
+                tpp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
+                dist.all_reduce(tpp, op=dist.ReduceOp.MAX)
+                th0 = time.perf_counter()
+                for _ in range(10):
+                    sl.both(*f, stencil=args.stencil, chunks=2)
+                hp = 1e3 * (time.perf_counter() - th0) / 10
+                torch.cuda.synchronize()
+                multi['pipelined'] = dict(chunks=2, value=pts * args.steps / float(tpp.item()), ms_per_step=1e3 * float(tpp.item()) / args.steps,
+                                          host_enqueue_ms_per_step=hp, unit='residual-updates/s',
+                                          note='the same step with the batch split into 2 chunks pipelined through pack / all-to-all / column pass / all-to-all / row pass')
             ph = slab_phases(sl, f, max(3, min(args.steps, 10)))
             keys = sorted(ph)
             t = torch.tensor([ph[k] for k in keys], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
@@ -449,8 +513,8 @@ def main():
         torch.cuda.synchronize()
         tb = (time.perf_counter() - ta) / 10
         alt = dict(ms_per_step=1e3 * tb, value=float(B) * n * n / tb, steps=10)
-    pts = float(B) * n * n
-    value = (1 if slab else world) * pts * args.steps / elapsed          # slab: the ranks share ONE batch of grids
+    if watchdog is not None:
+        watchdog.cancel()
 
     result = None
     if slab:                                   # per-kernel roofline is measured on whole grids: rebuild local full-size inputs
@@ -558,7 +622,9 @@ def main():
                                   parallelism=('row-slab x%d: the same %d grids on all ranks; halo send/recv + 2 all-to-all transposes per evaluation over %s'
                                                % (world, B, 'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)')) if slab
                                   else 'batch-sharded x%d (no data-path collective)' % world,
-                                  inputs='Taylor-Green t=0.1 + band-limited noise, nu=2pi/1000, dt=1e-3, resident in HBM'),
+                                  inputs='Taylor-Green t=0.1 + band-limited noise (seeds 1234 ...), nu=2pi/1000, dt=1e-3, resident in HBM; %d DISTINCT grids '
+                                         'generated on the host and tiled to the batch of %d (timing is data-independent; all %d grids are separate arrays in HBM)'
+                                         % (min(args.distinct, B), B, B)),
                       roofline=roofline)
         if multi is not None:
             result.update(multi)
@@ -572,9 +638,11 @@ def main():
                 result['secondary'] = bench_configs.secondary(cpu=not args.no_cpu_baseline)
             except Exception as e:                                 # noqa: BLE001 -- an extra object: never lose the headline line over it
                 result['secondary'] = dict(error=repr(e))
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             log('bench: timing the NumPy oracle on the host (bounded sample) ...')
-            result['cpu_baseline'] = cpu_baseline(n, check=check_out)
+            # N > 1: the same single-core sample on rank 0's host cores, shorter (the other ranks wait at the barrier below); the all-core row
+            # needs a fork before the GPU is touched and stays an N = 1 extra
+            result['cpu_baseline'] = cpu_baseline(n, budget_s=20.0 if world == 1 else 10.0, check=check_out)
             result['cpu_baseline']['all_cores'] = all_cores        # extra row: one oracle process per usable host core
         else:
             result['cpu_baseline'] = None

@@ -322,6 +322,29 @@ int nns_spec_residual_ypass_f32(const float* u, const float* v, const float* p, 
                                 const float* v_prev, float* r_u, float* r_v, float* r_div,
                                 int batch, int nx, int ny, double dt, double Ly,
                                 double rho, double nu, int precise, void* stream);
+/* The row passes on a ROW SLAB whose column-pass partials are read where the return all-to-all delivered them (round 4; no copy kernel
+ * between the collective and the row pass): part_u / part_v / part_div point at source rank 0's block of each partial field in a buffer laid
+ * out [src][field][batch][nx_local][seg_cols], seg_cols = ny / P; element (grid b, row i, column j) of a field sits at
+ * part + (j / seg_cols) * seg_stride + (b * nx_local + i) * seg_cols + j % seg_cols -- a row is P contiguous pieces of seg_cols floats.
+ * seg_cols: a power of two in [ny / 16, ny] (P <= 16: a register slot of a line never straddles two pieces); seg_stride >= batch * nx_local *
+ * seg_cols (3 x that for the [src][3 fields] buffer of nns/slab.py).  r_* / sp_r_*: row slabs [batch][nx_local][ny], written only.
+ * Same arithmetic per point as nns_spec_residual_ypass_f32 / nns_residual_both_rowpass_halo_f32 (bitwise the single-process result);
+ * ny: a power of two in [64, 1024] (the segmented layout exists for the FFT engine only).
+ * No reference counterpart: the reference runs on one device (src/neural_spectral/spectral_ode.py:155-156,165). */
+int nns_spec_residual_ypass_seg_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                    const float* part_u, const float* part_v, const float* part_div, int seg_cols, long seg_stride,
+                                    float* r_u, float* r_v, float* r_div, int batch, int nx, int ny, double dt, double Ly,
+                                    double rho, double nu, int precise, void* stream);
+int nns_residual_both_rowpass_halo_seg_f32(const float* u, const float* v, const float* p, const float* u_prev, const float* v_prev,
+                                           const float* halo_top, const float* halo_bot,
+                                           const float* part_u, const float* part_v, const float* part_div, int seg_cols, long seg_stride,
+                                           float* fd_r_u, float* fd_r_v, float* fd_r_div, float* sp_r_u, float* sp_r_v, float* sp_r_div,
+                                           int batch, int nx_local, int ny, long halo_field_stride, double dt, double dx, double Ly,
+                                           double rho, double nu, int precise, void* stream);
+/* The arithmetic a `precise` request resolves to for a WHOLE evaluation: 0 (all-float32 transforms on differenced lines) or 2 (float64
+ * forward transforms), from both transformed axes and the NNS_SPEC_F64 override -- the one policy implementation, for hosts that call the
+ * passes one by one (nns/slab.py). */
+int nns_spec_resolve_precise(int precise, double nu, int nx, double Lx, int ny, double Ly);
 /* Spectral derivatives of ONE real field (d/dx <-> i kx with the Nyquist mode dropped, lap <-> -|k|^2; definition
  * oracle/periodic.py: spectral_derivs): any of f_x, f_y, f_lap may be NULL.  precise as above. */
 int nns_spec_derivs_f32(const float* f, float* f_x, float* f_y, float* f_lap, int batch, int nx, int ny,
@@ -440,6 +463,14 @@ int nns_slab_transpose_pack_f32(const float* const* fields_host, int nfields, fl
 int nns_slab_transpose_pack_f64(const double* const* fields_host, int nfields, double* send, int batch, int nloc, int ny, int nranks, void* stream);
 int nns_slab_transpose_unpack_f32(const float* recv, float* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream);
 int nns_slab_transpose_unpack_f64(const double* recv, double* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream);
+/* transpose_pack of the batch chunk [grid0, grid0 + batch) of row slabs fields[f] [batch_total][nloc][ny] into send [d][f][batch][nloc][ny / nranks]
+ * AND, in the same launch, the halo messages of the WHOLE local batch: first[f][b][j] = fields[f][b][0][j], last[f][b][j] = fields[f][b][nloc-1][j],
+ * b < batch_total (first = last = NULL: the pack alone).  One launch where the slab step had three (round 4).  Needs 16-byte aligned pointers and
+ * ny / nranks a multiple of the 16-byte vector (NNS_ERR_UNSUPPORTED otherwise: use the separate calls). */
+int nns_slab_pack_halo_f32(const float* const* fields_host, int nfields, float* send, float* first, float* last, int batch_total, int grid0, int batch,
+                           int nloc, int ny, int nranks, void* stream);
+int nns_slab_pack_halo_f64(const double* const* fields_host, int nfields, double* send, double* first, double* last, int batch_total, int grid0, int batch,
+                           int nloc, int ny, int nranks, void* stream);
 
 #ifdef __cplusplus
 }

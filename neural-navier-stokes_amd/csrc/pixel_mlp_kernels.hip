@@ -319,20 +319,42 @@ int launch_fwd_uniform(const float* x, const float* weights, const float* biases
 // Per layer and tile: 8 + 8 + 8 (OT = 2) MFMA 32x32x16.  Partial gradients go to per-workgroup (OT = 2) or per-wave
 // (OT = 1) workspace slices; pixel_mlp_reduce_kernel adds the slices in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------------------------
+// LDS images of the bf16 backward kernels (round 4).  Four access patterns meet on them:
+//   (a) frag_w   the forward product's A fragments: lane (row r, half h) reads two 8-byte pieces of one weight row (ds_read2_b64);
+//   (b) frag_t   the transposed product's A fragments: ds_read_b64_tr_b16 over 4 rows x 16 columns per 16-lane group;
+//   (c) the chain waves' 8-byte stores of delta / activation rows into the [pixel][channel] images (ds_write_b64);
+//   (d) frag_pix the gradient waves' transposing reads of those images (the contraction over pixels).
+// Rounds 2-3 kept plain rows of 2 CH + 8 bytes: (a) and (c) conflict-free, but a transposing read's 32-lane half takes four rows at
+// 34-dword spacing -- rows q and q + 2 overlap on 12 of their 16 banks -- so EVERY (b) and (d) read took two LDS passes: 28 % of the
+// kernel's LDS-active cycles were bank conflicts (profiles/r03_mfma_pmc_final.csv) with the LDS 64 % busy.  Now an image is cut into
+// SUB-IMAGES of 16 columns, [column block][row][32 bytes]:
+//     byte(sub, row, slot) = sub * SUB + 32 row + 16 (row >> 3) + 8 (slot ^ ((row >> 2) & 1)),     slot = the 8-byte piece 0..3 of the row
+//   * a transposing read's four rows are 128 contiguous bytes, and the half's second 16-lane group reads the NEXT sub-image, SUB = 32 dwords
+//     (mod 64) further: 64 distinct banks;
+//   * 16 consecutive rows at one slot -- (a) and (c) -- hit 16 distinct bank pairs: 4 (row & 3) from the 32-byte rows, the XOR with row
+//     bit 2 and the 16-byte pad per 8 rows supply the other two bits;
+//   * every compile-time quantity (k-step, output tile, first / second piece, layer) stays an IMMEDIATE offset on one lane address.
+// tools/lds_banks.py replays the four patterns under the hardware's bank rules (old layout: 4 LDS cycles per transposing read, new: 2).
 template <int OT>
 struct BwdLds {
     static constexpr int SS = 2 * OT, CH = 32 * OT;
-#ifndef NNS_PM_ROWPAD
-#define NNS_PM_ROWPAD 8
-#endif
-    static constexpr int ROWB = CH * 2 + NNS_PM_ROWPAD;       // bytes per weight row / image row (8-byte multiple, skews banks)
-    static constexpr int W_BYTES = CH * ROWB;
+    static constexpr int NSUB = 2 * OT;                            // 16-column sub-images per image
+    static constexpr int sub_bytes(int nrows) {
+        const int b = nrows * 32 + (nrows / 8) * 16;
+        return b + ((32 - (b / 4) % 64 + 64) % 64) * 4;           // consecutive sub-images 32 banks apart
+    }
+    static constexpr int W_SUB = sub_bytes(CH), IMG_SUB = sub_bytes(128);
+    static constexpr int W_BYTES = NSUB * W_SUB;
     static constexpr int B_BYTES = CH * 4;
-    static constexpr int IMG_BYTES = 128 * ROWB;
+    static constexpr int IMG_BYTES = NSUB * IMG_SUB;
 #ifndef NNS_PM_IMGSETS
 #define NNS_PM_IMGSETS 2                                       // 2: the images are double-buffered over the layers (one barrier per layer)
 #endif
     __host__ __device__ static int total(int nl) { return nl * (W_BYTES + B_BYTES) + NNS_PM_IMGSETS * 2 * IMG_BYTES; }
+    // byte offset of the 8-byte piece `slot` of row `row` inside one sub-image
+    __host__ __device__ static constexpr int piece(int row, int slot) { return 32 * row + 16 * (row >> 3) + 8 * (slot ^ ((row >> 2) & 1)); }
+    // weight element (row = out, col = in) of a layer's image
+    __host__ __device__ static constexpr int w_elem(int row, int col) { return (col >> 4) * W_SUB + piece(row, (col & 15) >> 2) + 2 * (col & 3); }
 };
 
 __device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
@@ -341,33 +363,46 @@ __device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
     return r;
 }
 
-// A fragment of the forward product, rows 32 ot + r of the plain [out][in] image, k-step s
-template <int ROWB>
+// A fragment of the forward product: rows 32 ot + r of the weight image, k-step s (columns 16 s ..: sub-image s); lane half h takes the
+// pieces h and 2 + h of the row (channels 16 s + 4 h + 0..3 and 16 s + 8 + 4 h + 0..3: the accumulator-as-operand k order).  One ds_read2_b64.
+template <int OT>
 __device__ __forceinline__ bf16x8 frag_w(const unsigned char* wimg, int r, int h, int ot, int s) {
-    const unsigned char* a = wimg + (32 * ot + r) * ROWB + (16 * s + 4 * h) * 2;
+    using U = BwdLds<OT>;
+    const unsigned char* a = wimg + (32 * r + 16 * (r >> 3) + 8 * (h ^ ((r >> 2) & 1))) + (s * U::W_SUB + ot * (32 * 32 + 4 * 16));
     return join8(*reinterpret_cast<const bf16x4*>(a), *reinterpret_cast<const bf16x4*>(a + 16));
 }
 
-// Transposing fragment read: element j of lane (r, h) = M[row0 + 16 s + 8 (j>>2) + 4 h + (j&3)][col_block + r] of a plain
-// [rows][cols] bf16 image (row stride ROWB bytes).  Lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of
-// the group's 4 x 16 block; lane i receives column i of the four rows.  EXEC must be all ones here.
-template <int ROWB>
+// The lane part of a transposing read's address (frag_t, frag_pix): lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the
+// group's 4 x 16 block; the half's second group (lane bit 4) reads the next sub-image; lane half h' takes rows +4.
+template <int SUB>
+__device__ __forceinline__ int tr_lane(int lane) {
+    const int gl = lane & 15, q = gl >> 2, pp = gl & 3, hp = lane >> 5;
+    return ((lane >> 4) & 1) * SUB + (4 * hp + q) * 32 + 8 * (pp ^ hp);
+}
+// Transposing fragment read: element j of lane (r, h) = M[16 s + 8 (j>>2) + 4 h + (j&3)][col_block + r] of a weight image (rows = out).
+// Lane i of a group receives column i of the four rows.  EXEC must be all ones here.
+template <int OT>
 __device__ __forceinline__ bf16x8 frag_t(const unsigned char* img, int lane, int s, int col_block) {
-    const int gl = lane & 15, q = gl >> 2, pp = gl & 3;
-    const int c0 = col_block + 16 * ((lane >> 4) & 1), row0 = 16 * s + 4 * (lane >> 5);
-    const unsigned char* a0 = img + (row0 + q) * ROWB + (c0 + 4 * pp) * 2;
+    using U = BwdLds<OT>;
+    const unsigned char* a0 = img + tr_lane<U::W_SUB>(lane) + ((col_block >> 4) * U::W_SUB + s * (16 * 32 + 2 * 16));
     using lds_v4 = __attribute__((address_space(3))) bf16x4;
-    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 8 * ROWB)));
+    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + (8 * 32 + 16))));
 }
 
-// 8 consecutive pixels (16 s + 8 h .. +7) of channel ch_block + r from a [pix][ch] image
-template <int ROWB>
+// 8 pixels of channel ch_block + r from a [pix][ch] image for the contraction over pixels: element j of lane (r, h) = pixel
+// 16 s + 8 (j>>2) + 4 h + (j&3) (the same k order for both operands of the product; round 3 used 16 s + 8 h + j)
+template <int OT>
 __device__ __forceinline__ bf16x8 frag_pix(const unsigned char* img, int lane, int s, int ch_block) {
-    const int gl = lane & 15, q = gl >> 2, pp = gl & 3;
-    const int c0 = ch_block + 16 * ((lane >> 4) & 1), pix0 = 16 * s + 8 * (lane >> 5);
-    const unsigned char* a0 = img + (pix0 + q) * ROWB + (c0 + 4 * pp) * 2;
+    using U = BwdLds<OT>;
+    const unsigned char* a0 = img + tr_lane<U::IMG_SUB>(lane) + (ch_block >> 4) * U::IMG_SUB + s * (16 * 32 + 2 * 16);
     using lds_v4 = __attribute__((address_space(3))) bf16x4;
-    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ROWB)));
+    return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + (8 * 32 + 16))));
+}
+// The lane part of the chain waves' image row stores: row 32 wave + r, piece h (+ 2 for the fragment's second half), sub-image = k-step
+template <int OT>
+__device__ __forceinline__ int img_row_lane(int wave, int r, int h) {
+    const int row = 32 * wave + r;
+    return 32 * row + 16 * (row >> 3) + 8 * (h ^ ((row >> 2) & 1));
 }
 
 template <int OT, bool SMALL>
@@ -403,7 +438,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
                                                                      float* __restrict__ gx, float* __restrict__ ws,
                                                                      long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
     using U = BwdLds<OT>;
-    constexpr int SS = U::SS, ROWB = U::ROWB;
+    constexpr int SS = U::SS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nl = d.nlayers;
     {   // stage: zero everything (pads, images), then scatter the real matrices (coalesced reads)
@@ -417,7 +452,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
             int row = threadIdx.x / cin, k = threadIdx.x - row * cin;
             const int drow = 256 / cin, dk = 256 - drow * cin;
             for (int e = threadIdx.x; e < n; e += 256) {
-                *reinterpret_cast<unsigned short*>(dst + row * ROWB + k * 2) = f2bf(Wl[e]);
+                *reinterpret_cast<unsigned short*>(dst + U::w_elem(row, k)) = f2bf(Wl[e]);
                 row += drow; k += dk;
                 if (k >= cin) { k -= cin; ++row; }
             }
@@ -464,7 +499,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[ot][i] = bl[32 * ot + acc_row(i, h)];
 #pragma unroll
-                    for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<ROWB>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
+                    for (int s = 0; s < SS; ++s) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_w<OT>(wimg, r, h, ot, s), afrag[l][s], acc[ot], 0, 0, 0);
                 }
 #pragma unroll
                 for (int s = 0; s < SS; ++s) afrag[l + 1][s] = pack8<true>(acc[s >> 1], 8 * (s & 1));
@@ -490,7 +525,7 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 #pragma unroll
                     for (int i = 0; i < 16; ++i) nd[it][i] = 0.f;
 #pragma unroll
-                    for (int s = 0; s < SS; ++s) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<ROWB>(wimg, lane, s, 32 * it), dfrag[s], nd[it], 0, 0, 0);
+                    for (int s = 0; s < SS; ++s) nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_t<OT>(wimg, lane, s, 32 * it), dfrag[s], nd[it], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // Consecutive layers use alternate image sets: a wave may write layer l-1's images while slower waves still read
@@ -499,22 +534,22 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
                 unsigned char* imgD = img0 + (NNS_PM_IMGSETS == 2 ? (l & 1) : 0) * 2 * U::IMG_BYTES;
                 unsigned char* imgA = imgD + U::IMG_BYTES;
                 {   // delta_l and a_{l-1} as bf16 rows [32 wave + r] of the images
-                    unsigned char* rowD = imgD + (32 * wave + r) * ROWB;
-                    unsigned char* rowA = imgA + (32 * wave + r) * ROWB;
+                    unsigned char* rowD = imgD + img_row_lane<OT>(wave, r, h);
+                    unsigned char* rowA = imgA + img_row_lane<OT>(wave, r, h);
 #pragma unroll
                     for (int s = 0; s < SS; ++s) {
-                        // fragment elements 0..3 = channels 16 s + 4 h + (0..3), elements 4..7 = channels 16 s + 8 + 4 h + (0..3)
-                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 0, 1, 2, 3);
-                        *reinterpret_cast<bf16x4*>(rowD + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
-                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 0, 1, 2, 3);
-                        *reinterpret_cast<bf16x4*>(rowA + (16 * s + 8 + 4 * h) * 2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
+                        // fragment elements 0..3 = channels 16 s + 4 h + (0..3): piece h of sub-image s; elements 4..7 = channels 16 s + 8 + 4 h + (0..3): piece 2 + h
+                        *reinterpret_cast<bf16x4*>(rowD + s * U::IMG_SUB) = __builtin_shufflevector(dfrag[s], dfrag[s], 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(rowD + s * U::IMG_SUB + 16) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
+                        *reinterpret_cast<bf16x4*>(rowA + s * U::IMG_SUB) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 0, 1, 2, 3);
+                        *reinterpret_cast<bf16x4*>(rowA + s * U::IMG_SUB + 16) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
                     }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    const bf16x8 fa = frag_pix<ROWB>(imgD, lane, ks0 + kk, 32 * bo);
-                    const bf16x8 fb = frag_pix<ROWB>(imgA, lane, ks0 + kk, 32 * bi);
+                    const bf16x8 fa = frag_pix<OT>(imgD, lane, ks0 + kk, 32 * bo);
+                    const bf16x8 fb = frag_pix<OT>(imgA, lane, ks0 + kk, 32 * bi);
                     gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
                     if (kk & 1) __builtin_amdgcn_sched_barrier(0);
                     if (do_gb) {
@@ -598,7 +633,6 @@ __device__ __forceinline__ bf16x8 raw8(const f32x16& a, int base) { const i32x4v
 template <int OT>
 __device__ __forceinline__ void bwd_stage(unsigned char* lds, const float* __restrict__ W, const float* __restrict__ Bv, const PixelMlpDesc& d) {
     using U = BwdLds<OT>;
-    constexpr int ROWB = U::ROWB;
     const int nl = d.nlayers;
     {
         const int total = U::total(nl);
@@ -617,7 +651,7 @@ __device__ __forceinline__ void bwd_stage(unsigned char* lds, const float* __res
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int e = e0 + q * 512;
-                        if (e < n) { const int row = (int)(((unsigned)e * magic) >> 20); *reinterpret_cast<unsigned short*>(dst + row * ROWB + (e - row * cin) * 2) = f2bf(vq[q]); }
+                        if (e < n) { const int row = (int)(((unsigned)e * magic) >> 20); *reinterpret_cast<unsigned short*>(dst + U::w_elem(row, e - row * cin)) = f2bf(vq[q]); }
                     }
                 }
             }
@@ -633,7 +667,6 @@ template <int OT>
 __device__ __forceinline__ void bwd_gradient_waves(unsigned char* img0, int wave, int lane, long nsuper, const PixelMlpDesc& d,
                                                    float* __restrict__ ws, int nparams_w, int nparams) {
     using U = BwdLds<OT>;
-    constexpr int ROWB = U::ROWB;
     const int nl = d.nlayers, r = lane & 31, h = lane >> 5;
     // ================= gradient waves =================
     const int gwv = wave - 4;
@@ -667,12 +700,12 @@ __device__ __forceinline__ void bwd_gradient_waves(unsigned char* img0, int wave
                     bf16x8 fa_r[GD], fb_r[GD];
                     float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<ROWB>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<ROWB>(imgA, lane, ks0 + q, 32 * bi); }
+                    for (int q = 0; q < GD; ++q) { fa_r[q] = frag_pix<OT>(imgD, lane, ks0 + q, 32 * bo); fb_r[q] = frag_pix<OT>(imgA, lane, ks0 + q, 32 * bi); }
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk) {
                         const bf16x8 fa = fa_r[kk % GD], fb = fb_r[kk % GD];
                         if (!PMB(3)) gw[l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, gw[l], 0, 0, 0);
-                        if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<ROWB>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<ROWB>(imgA, lane, ks0 + kk + GD, 32 * bi); }
+                        if (kk + GD < KS) { fa_r[kk % GD] = frag_pix<OT>(imgD, lane, ks0 + kk + GD, 32 * bo); fb_r[kk % GD] = frag_pix<OT>(imgA, lane, ks0 + kk + GD, 32 * bi); }
                         if (kk & 1) __builtin_amdgcn_sched_barrier(0);
                         if constexpr (with_gb) {
                             const bf16x2v ones = {(__bf16)1.0f, (__bf16)1.0f};
@@ -715,7 +748,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                                                                    float* __restrict__ gx, float* __restrict__ ws,
                                                                    long npix_total, int P, PixelMlpDesc d, int nparams_w, int nparams) {
     using U = BwdLds<OT>;
-    constexpr int SS = U::SS, ROWB = U::ROWB;
+    constexpr int SS = U::SS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nl = d.nlayers;
     bwd_stage<OT>(lds, W, Bv, d);
@@ -778,7 +811,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
         static_assert(NM % D == 0, "ring slots must line up across layers");
         bf16x8 wr[D];
 #pragma unroll
-        for (int q = 0; q < D; ++q) wr[q] = frag_w<ROWB>(lds, r, h, q / SS, q % SS);
+        for (int q = 0; q < D; ++q) wr[q] = frag_w<OT>(lds, r, h, q / SS, q % SS);
         f32x16 accb[2][OT];                                                                        // accumulators by layer parity: the other set takes the next bias
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot)
@@ -800,8 +833,8 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 static_for<0, NM>([&](auto ic) {
                     constexpr int idx = decltype(ic)::value, ot = idx / SS, s2 = idx % SS, nx = idx + D;
                     acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PMB(1) ? afrag[l][(s2 + 1) % SS] : wr[idx % D], afrag[l][s2], acc[ot], 0, 0, 0);
-                    if constexpr (nx < NM) wr[idx % D] = frag_w<ROWB>(wimg, r, h, nx / SS, nx % SS);
-                    else wr[idx % D] = frag_w<ROWB>(wnext, r, h, (nx - NM) / SS, (nx - NM) % SS);
+                    if constexpr (nx < NM) wr[idx % D] = frag_w<OT>(wimg, r, h, nx / SS, nx % SS);
+                    else wr[idx % D] = frag_w<OT>(wnext, r, h, (nx - NM) / SS, (nx - NM) % SS);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              // a frag_w is one ds_read2_b64
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 });
@@ -844,7 +877,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
 #endif
         bf16x8 tr[D];
 #pragma unroll
-        for (int q = 0; q < D; ++q) tr[q] = frag_t<ROWB>(lds + (nl - 1) * U::W_BYTES, lane, kBwdAlt ? q / OT : q % SS, 32 * (kBwdAlt ? q % OT : q / SS));
+        for (int q = 0; q < D; ++q) tr[q] = frag_t<OT>(lds + (nl - 1) * U::W_BYTES, lane, kBwdAlt ? q / OT : q % SS, 32 * (kBwdAlt ? q % OT : q / SS));
 #pragma unroll
         for (int l = kMaxLayers - 1; l >= 0; --l) {
             if (l < nl) {
@@ -863,13 +896,13 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 // delta_l and a_{l-1} are known on entry: their image rows are stored UNDER the layer's MFMAs (the set is free once the barrier of
                 // layer l + 1 is behind this wave), so that only the barrier itself stands between the last MFMA and the mask / convert step.
                 unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
-                unsigned char* rowD = imgD + (32 * wave + r) * ROWB + 8 * h;
+                unsigned char* rowD = imgD + img_row_lane<OT>(wave, r, h);
                 unsigned char* rowA = rowD + U::IMG_BYTES;
                 static_for<0, NM>([&](auto ic) {
                     constexpr int idx = decltype(ic)::value, it = kBwdAlt ? idx % OT : idx / SS, s2 = kBwdAlt ? idx / OT : idx % SS, nx = idx + D;
                     constexpr int nit = kBwdAlt ? nx % OT : (nx % NM) / SS, ns2 = kBwdAlt ? (nx % NM) / OT : nx % SS;
                     nd[it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PMB(1) ? dfrag[(s2 + 1) % SS] : tr[idx % D], dfrag[s2], nd[it], 0, 0, 0);
-                    tr[idx % D] = frag_t<ROWB>(nx < NM ? wimg : wprev, lane, ns2, 32 * nit);
+                    tr[idx % D] = frag_t<OT>(nx < NM ? wimg : wprev, lane, ns2, 32 * nit);
                     constexpr int per = 4 * SS / NM;                                                // 8-byte image stores per MFMA
                     if (!PMB(6)) {
 #pragma unroll
@@ -877,7 +910,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                             const int k = idx * per + j, s = k >> 2;
                             const bf16x8 src = (k & 2) ? afrag[l][s] : dfrag[s];
                             unsigned char* row = (k & 2) ? rowA : rowD;
-                            *reinterpret_cast<bf16x4*>(row + (16 * s + 8 * (k & 1)) * 2) = (k & 1) ? __builtin_shufflevector(src, src, 4, 5, 6, 7) : __builtin_shufflevector(src, src, 0, 1, 2, 3);
+                            *reinterpret_cast<bf16x4*>(row + s * U::IMG_SUB + 16 * (k & 1)) = (k & 1) ? __builtin_shufflevector(src, src, 4, 5, 6, 7) : __builtin_shufflevector(src, src, 0, 1, 2, 3);
                         }
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

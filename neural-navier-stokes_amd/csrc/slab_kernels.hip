@@ -93,6 +93,56 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(Ptr4<T> rows_in, MPt
     }
 }
 
+// transpose_pack of the batch chunk [g0, g0 + Bc) AND the halo messages of the WHOLE local batch in one launch (round 4: the slab step's
+// two gather_lines launches folded into the first chunk's pack): the trailing workgroups of the grid copy row 0 of every grid into
+// first[f][b][ny] and row nloc - 1 into last[f][b][ny].
+template <typename T>
+__global__ __launch_bounds__(256) void pack_halo_vec_kernel(Ptr4<T> rows_in, T* __restrict__ buf, T* __restrict__ first, T* __restrict__ last,
+                                                            long Btot, long g0, long Bc, long nloc, long ny, long P, unsigned pack_blocks) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    using V = __attribute__((ext_vector_type(VW))) T;
+    const long f = blockIdx.z, F = gridDim.z;
+    const long vpr = ny / VW;
+    if (blockIdx.x < pack_blocks) {
+        const long nyl = ny / P, nlines = Bc * nloc, total = nlines * vpr;
+        const T* src = rows_in.p[f] + g0 * nloc * ny;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)pack_blocks * 256) {
+            const long bi = e / vpr, j = (e - bi * vpr) * VW;
+            const long d = j / nyl, jj = j - d * nyl;
+            *reinterpret_cast<V*>(buf + ((d * F + f) * Bc * nloc + bi) * nyl + jj) = *reinterpret_cast<const V*>(src + bi * ny + j);
+        }
+    } else {
+        const long total = 2 * Btot * vpr, hb = gridDim.x - pack_blocks;
+        for (long e = (long)(blockIdx.x - pack_blocks) * 256 + threadIdx.x; e < total; e += hb * 256) {
+            const long which = e / (Btot * vpr), r = e - which * Btot * vpr;
+            const long b = r / vpr, j = (r - b * vpr) * VW;
+            T* dst = (which ? last : first) + (f * Btot + b) * ny + j;
+            *reinterpret_cast<V*>(dst) = *reinterpret_cast<const V*>(rows_in.p[f] + (b * nloc + (which ? nloc - 1 : 0)) * ny + j);
+        }
+    }
+}
+
+template <typename T>
+int pack_halo(const T* const* fields, int nfields, T* send, T* first, T* last, int Btot, int g0, int Bc, int nloc, int ny, int P, hipStream_t s) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    if (!fields || !send || nfields < 1 || nfields > 4 || Btot < 1 || g0 < 0 || Bc < 1 || g0 + Bc > Btot || nloc < 1 || ny < 1 || P < 1 || ny % P || (first == nullptr) != (last == nullptr))
+        return fail(NNS_ERR_INVALID_ARG, "slab pack_halo: bad args (nfields=%d Btot=%d g0=%d Bc=%d nloc=%d ny=%d P=%d)", nfields, Btot, g0, Bc, nloc, ny, P);
+    bool vec = (ny / P) % VW == 0 && reinterpret_cast<uintptr_t>(send) % 16 == 0 && reinterpret_cast<uintptr_t>(first) % 16 == 0 && reinterpret_cast<uintptr_t>(last) % 16 == 0;
+    for (int f = 0; f < nfields; ++f) {
+        if (!fields[f]) return fail(NNS_ERR_INVALID_ARG, "slab pack_halo: field %d is NULL", f);
+        vec = vec && reinterpret_cast<uintptr_t>(fields[f]) % 16 == 0;
+    }
+    if (!vec) return fail(NNS_ERR_UNSUPPORTED, "slab pack_halo: needs 16-byte aligned fields / buffers and ny / P a multiple of %d (use the separate pack and gather calls)", VW);
+    Ptr4<T> in{};
+    for (int f = 0; f < nfields; ++f) in.p[f] = fields[f];
+    const long total = (long)Bc * nloc * (ny / VW);
+    long pb = (total + 255) / 256; if (pb > 16384) pb = 16384;
+    long hb = first ? (2L * Btot * (ny / VW) + 255) / 256 : 0; if (hb > 1024) hb = 1024;
+    hipLaunchKernelGGL(pack_halo_vec_kernel<T>, dim3((unsigned)(pb + hb), 1, (unsigned)nfields), dim3(256), 0, s, in, send, first, last,
+                       (long)Btot, (long)g0, (long)Bc, (long)nloc, (long)ny, (long)P, (unsigned)pb);
+    return check_launch("slab_pack_halo");
+}
+
 template <typename T>
 int transpose(bool pack, const T* const* fields, int nfields, T* buf, int B, int nloc, int ny, int P, hipStream_t s) {
     if (!fields || !buf || nfields < 1 || nfields > 4 || B < 1 || nloc < 1 || ny < 1 || P < 1 || ny % P || (long)B * nloc > 0x7fffffffL)
@@ -156,6 +206,14 @@ NNS_API int nns_slab_transpose_pack_f32(const float* const* fields_host, int nfi
 }
 NNS_API int nns_slab_transpose_pack_f64(const double* const* fields_host, int nfields, double* send, int batch, int nloc, int ny, int nranks, void* stream) {
     return transpose<double>(true, fields_host, nfields, send, batch, nloc, ny, nranks, S(stream));
+}
+NNS_API int nns_slab_pack_halo_f32(const float* const* fields_host, int nfields, float* send, float* first, float* last, int batch_total, int grid0, int batch,
+                                   int nloc, int ny, int nranks, void* stream) {
+    return pack_halo<float>(fields_host, nfields, send, first, last, batch_total, grid0, batch, nloc, ny, nranks, S(stream));
+}
+NNS_API int nns_slab_pack_halo_f64(const double* const* fields_host, int nfields, double* send, double* first, double* last, int batch_total, int grid0, int batch,
+                                   int nloc, int ny, int nranks, void* stream) {
+    return pack_halo<double>(fields_host, nfields, send, first, last, batch_total, grid0, batch, nloc, ny, nranks, S(stream));
 }
 NNS_API int nns_slab_transpose_unpack_f32(const float* recv, float* const* fields_host, int nfields, int batch, int nloc, int ny, int nranks, void* stream) {
     return transpose<float>(false, fields_host, nfields, const_cast<float*>(recv), batch, nloc, ny, nranks, S(stream));

@@ -54,6 +54,7 @@ _DUAL = {
     'nns_slab_scatter_lines': [_P, _PP, _I] + [_L] * 5 + [_P],
     'nns_slab_transpose_pack': [_PP, _I, _P] + [_I] * 4 + [_P],
     'nns_slab_transpose_unpack': [_P, _PP, _I] + [_I] * 4 + [_P],
+    'nns_slab_pack_halo': [_PP, _I, _P, _P, _P] + [_I] * 6 + [_P],
 }
 _SINGLE = {
     'nns_spec_residual_f32': [_P] * 8 + [_I] * 3 + [_D] * 5 + [_I, _P],
@@ -64,6 +65,9 @@ _SINGLE = {
     'nns_spec_residual_xpass_seg_f32': [_P] * 6 + [_I] * 4 + [_L] + [_D] * 3 + [_I, _P],
     'nns_residual_both_rowpass_halo_f32': [_P] * 13 + [_I] * 3 + [_L] + [_D] * 5 + [_I, _P],
     'nns_spec_residual_ypass_f32': [_P] * 8 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_spec_residual_ypass_seg_f32': [_P] * 8 + [_I, _L] + [_P] * 3 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_residual_both_rowpass_halo_seg_f32': [_P] * 10 + [_I, _L] + [_P] * 6 + [_I] * 3 + [_L] + [_D] * 5 + [_I, _P],
+    'nns_spec_resolve_precise': [_I, _D, _I, _D, _I, _D],
     'nns_spec_derivs_f32': [_P] * 4 + [_I] * 3 + [_D, _D, _I, _P],
     'nns_spec_rfft2_f32': [_P, _P, _I, _I, _I, _P],
     'nns_spec_irfft2_f32': [_P, _P, _I, _I, _I, _P],

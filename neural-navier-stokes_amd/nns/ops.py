@@ -344,6 +344,59 @@ def residual_both_rowpass_halo(u, v, p, u_prev, v_prev, halo_top, halo_bot, sp_p
     return fo, so
 
 
+def _seg_parts(got, B, nx, ny, what):
+    """got [P, 3, B, nx, ny / P] (the receive buffer of the return all-to-all) -> (the three fields' pointers of source rank 0, seg_cols, seg_stride)."""
+    _f32(got)
+    P = got.shape[0] if got.dim() == 5 else 0
+    if P < 1 or ny % P or tuple(got.shape) != (P, 3, B, nx, ny // P):
+        raise ValueError("%s: partials must be [P, 3, %d, %d, ny / P] float32, got %s" % (what, B, nx, tuple(got.shape)))
+    fs = B * nx * (ny // P)
+    return [got.data_ptr() + f * fs * 4 for f in range(3)], ny // P, 3 * fs
+
+
+def residual_both_rowpass_halo_seg(u, v, p, u_prev, v_prev, halo_top, halo_bot, got, dt, dx, Ly, rho, nu, precise=True, out_fd=None, out_spec=None, halo_grid0=0):
+    """The fused row pass on a row slab with its column-pass partials read IN PLACE from `got` [P, 3, B, nloc, ny / P], the receive buffer
+    of the slab step's return all-to-all (nns_residual_both_rowpass_halo_seg_f32): no scatter copy in between.  Returns
+    ((fd r_u, r_v, r_div), (spectral r_u, r_v, r_div)), both as row slabs.  halo_top / halo_bot / halo_grid0 as residual_both_rowpass_halo."""
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
+    if suf != '_f32':
+        raise TypeError("residual_both_rowpass_halo_seg: float32 fields")
+    Bh = halo_top.shape[1] if halo_top.dim() == 3 else -1
+    for h in (halo_top, halo_bot):
+        if not (h.is_cuda and h.is_contiguous() and h.dtype == u.dtype and tuple(h.shape) == (3, Bh, ny) and 0 <= halo_grid0 and halo_grid0 + B <= Bh):
+            raise ValueError("residual_both_rowpass_halo_seg: halo messages must be contiguous [3, >= %d, %d] float32 device tensors" % (halo_grid0 + B, ny))
+    parts, seg_cols, seg_stride = _seg_parts(got, B, nx, ny, 'residual_both_rowpass_halo_seg')
+    fo = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
+    so = out_spec if out_spec is not None else tuple(torch.empty_like(u) for _ in range(3))
+    _chk(u, *fo, *so)
+    off = halo_grid0 * ny * 4
+    check(_lib.lib().nns_residual_both_rowpass_halo_seg_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), _p(halo_top) + off, _p(halo_bot) + off,
+                                                            parts[0], parts[1], parts[2], seg_cols, seg_stride,
+                                                            _p(fo[0]), _p(fo[1]), _p(fo[2]), _p(so[0]), _p(so[1]), _p(so[2]), B, nx, ny, Bh * ny,
+                                                            dt, dx, Ly, rho, nu, _prec(precise), _stream()), 'nns_residual_both_rowpass_halo_seg_f32')
+    return fo, so
+
+
+def spec_residual_ypass_seg(u, v, p, u_prev, v_prev, got, dt, Ly, rho, nu, precise=True, out=None):
+    """The spectral row pass with its partials read in place from `got` [P, 3, B, nloc, ny / P] (nns_spec_residual_ypass_seg_f32)."""
+    suf, (B, nx, ny) = _chk(u, v, p, u_prev, v_prev)
+    if suf != '_f32':
+        raise TypeError("spec_residual_ypass_seg: float32 fields")
+    parts, seg_cols, seg_stride = _seg_parts(got, B, nx, ny, 'spec_residual_ypass_seg')
+    ro = out if out is not None else tuple(torch.empty_like(u) for _ in range(3))
+    _chk(u, *ro)
+    check(_lib.lib().nns_spec_residual_ypass_seg_f32(_p(u), _p(v), _p(p), _p(u_prev), _p(v_prev), parts[0], parts[1], parts[2], seg_cols, seg_stride,
+                                                     _p(ro[0]), _p(ro[1]), _p(ro[2]), B, nx, ny, dt, Ly, rho, nu, _prec(precise), _stream()),
+          'nns_spec_residual_ypass_seg_f32')
+    return ro
+
+
+def spec_resolve_precise(precise, nu, nx, Lx, ny, Ly):
+    """The arithmetic a `precise` request resolves to for a whole evaluation: 0 or 2 (nns_spec_resolve_precise: the library's one policy,
+    NNS_SPEC_F64 included)."""
+    return int(_lib.lib().nns_spec_resolve_precise(_prec(precise), float(nu), int(nx), float(Lx), int(ny), float(Ly)))
+
+
 # ----------------------------------------------------------------------------- slab message packing (nns/slab.py)
 def _ptr_array(ts):
     import ctypes
@@ -389,6 +442,23 @@ def slab_transpose_pack(fields, send, P):
     if not (send.is_cuda and send.is_contiguous() and send.dtype == fields[0].dtype and tuple(send.shape) == (P, len(fields), B, nloc, ny // P) and ny % P == 0):
         raise ValueError("slab_transpose_pack: send must be [%d, %d, %d, %d, %d]" % (P, len(fields), B, nloc, ny // P))
     _call('nns_slab_transpose_pack', suf, _ptr_array(fields), len(fields), _p(send), B, nloc, ny, P, _stream())
+    return send
+
+
+def slab_pack_halo(fields, send, first, last, g0, P):
+    """transpose_pack of grids [g0, g0 + Bc) of the row slabs fields[f] [B, nloc, ny] into send [P, F, Bc, nloc, ny / P] and -- first / last not
+    None -- the edge rows of ALL B grids into first / last [F, B, ny], in ONE launch (nns_slab_pack_halo_*)."""
+    suf = _slab_fields(fields, 'slab_pack_halo')
+    B, nloc, ny = fields[0].shape
+    F = len(fields)
+    Bc = send.shape[2] if send.dim() == 5 else -1
+    if not (send.is_cuda and send.is_contiguous() and send.dtype == fields[0].dtype and ny % P == 0 and tuple(send.shape) == (P, F, Bc, nloc, ny // P) and 0 <= g0 and g0 + Bc <= B):
+        raise ValueError("slab_pack_halo: send must be [%d, %d, Bc, %d, %d] with g0 + Bc <= %d" % (P, F, nloc, ny // P, B))
+    for h in (first, last):
+        if h is not None and not (h.is_cuda and h.is_contiguous() and h.dtype == fields[0].dtype and tuple(h.shape) == (F, B, ny)):
+            raise ValueError("slab_pack_halo: first / last must be contiguous [%d, %d, %d]" % (F, B, ny))
+    _call('nns_slab_pack_halo', suf, _ptr_array(fields), F, _p(send), _p(first) if first is not None else None, _p(last) if last is not None else None,
+          B, int(g0), Bc, nloc, ny, P, _stream())
     return send
 
 

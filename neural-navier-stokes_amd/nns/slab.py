@@ -12,11 +12,12 @@ rehearsal of the HIP path, see nns/_comm.py).
   * spectral residual: the y-pass (rows) is local.  The x-pass needs complete columns: ONE kernel writes the all-to-all send
     buffer [dest][u, v, p][B][nloc][ny/P], ONE all-to-all delivers [src][u, v, p][B][nloc][ny/P], the column pass READS THAT
     LAYOUT IN PLACE (rows in blocks of nloc per source rank) and writes its three partials in the same layout, which is
-    the send buffer of the return all-to-all; ONE kernel scatters the returned blocks back into row slabs.  2 collectives
-    and 2 copy kernels per evaluation (a library-style 2-D FFT per derivative would need 10 transposes).
-  * both (the metric's unit, 5-point stencil): the halo exchange is started first and travels under the two transposes and the
-    column pass; the row pass then evaluates the stencil AND finishes the spectral residual in one launch
-    (nns_residual_both_rowpass_halo_f32) -- the fused form of the single-GPU headline.
+    the send buffer of the return all-to-all; the row pass READS THE RETURNED BLOCKS IN PLACE too (a row = P pieces of ny/P
+    floats, nns_spec_residual_ypass_seg_f32).  2 collectives and 1 copy kernel per evaluation (round 3: 2 copy kernels; a
+    library-style 2-D FFT per derivative would need 10 transposes).
+  * both (the metric's unit, 5-point stencil): the pack launch of the first batch chunk also packs the two halo messages; they
+    travel under the two transposes and the column pass; the row pass then evaluates the stencil AND finishes the spectral
+    residual in one launch (nns_residual_both_rowpass_halo_seg_f32) -- the fused form of the single-GPU headline.
   * SOR in the reference's lexicographic order does not shard (sequential fronts): replicas only.  The opt-in
     RED-BLACK order does (SlabPressure below): one halo exchange per half-sweep and one all-reduce(max) per sweep, all
     enqueued ahead with device-side stopping.
@@ -51,6 +52,22 @@ class HipCompute(object):
         from . import ops
         return ops.slab_transpose_unpack(recv, fields, P)
 
+    def pack_halo(self, fields, send, first, last, g0, P):
+        """Grids [g0, g0 + Bc) of the row slabs -> the all-to-all send buffer, and (first / last not None) the edge rows of ALL grids -> the two
+        halo messages: ONE launch (nns_slab_pack_halo_*) when the 16-byte vector path applies, the separate kernels otherwise."""
+        from . import ops
+        f0 = fields[0]
+        B, nloc, ny = f0.shape
+        vw = 16 // f0.element_size()
+        aligned = all(t.data_ptr() % 16 == 0 for t in list(fields) + [send] + ([first, last] if first is not None else []))
+        if aligned and (ny // P) % vw == 0:
+            return ops.slab_pack_halo(fields, send, first, last, g0, P)
+        ops.slab_transpose_pack([t[g0:g0 + send.shape[2]] for t in fields], send, P)
+        if first is not None:
+            ops.slab_gather_lines(fields, first, B, nloc * ny, 0, ny)
+            ops.slab_gather_lines(fields, last, B, nloc * ny, (nloc - 1) * ny, ny)
+        return send
+
     def fd_residual_halo(self, u, v, p, up, vp, top, bot, dt, dx, dy, rho, nu, stencil, rows, out):
         from . import ops
         return ops.fd_residual_halo(u, v, p, up, vp, top, bot, dt, dx, dy, rho, nu, stencil, rows, out)
@@ -63,16 +80,27 @@ class HipCompute(object):
         from . import ops
         return ops.spec_residual_ypass_(u, v, p, up, vp, ru, rv, rd, dt, Ly, rho, nu, precise)
 
+    def spec_ypass_seg(self, u, v, p, up, vp, got, out, dt, Ly, rho, nu, precise):
+        from . import ops
+        return ops.spec_residual_ypass_seg(u, v, p, up, vp, got, dt, Ly, rho, nu, precise, out=out)
+
     def both_rowpass_halo(self, u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=None, halo_grid0=0):
         from . import ops
         return ops.residual_both_rowpass_halo(u, v, p, up, vp, top, bot, partials, dt, dx, Ly, rho, nu, precise, out_fd=out_fd, halo_grid0=halo_grid0)
 
+    def both_rowpass_halo_seg(self, u, v, p, up, vp, top, bot, got, dt, dx, Ly, rho, nu, precise, out_fd, out_spec, halo_grid0=0):
+        from . import ops
+        return ops.residual_both_rowpass_halo_seg(u, v, p, up, vp, top, bot, got, dt, dx, Ly, rho, nu, precise, out_fd=out_fd, out_spec=out_spec, halo_grid0=halo_grid0)
+
+    def resolve_precise(self, precise, nu, nx, Lx, ny, Ly):
+        from . import ops
+        return ops.spec_resolve_precise(precise, nu, nx, Lx, ny, Ly)
+
 
 class SlabResidual(object):
     def __init__(self, nx, ny, dt, rho, nu, Lx=2 * math.pi, Ly=2 * math.pi, group=None, compute=None, precise=True, chunks=None, loopback=None):
-        """chunks: how many batch chunks `both` / `spectral` pipeline through their stages (None: 2 on a stream-ordered transport
-        with more than one rank, 1 otherwise -- see `_pipeline`; every chunk costs the host ~0.1 ms of Python to enqueue, so more
-        chunks than the device time of a step can hide make the step host-bound)."""
+        """chunks: how many batch chunks `both` / `spectral` pipeline through their stages (None: 1 -- see `_nchunks`; every chunk costs
+        the host ~0.1 ms of Python to enqueue, so more chunks than the device time of a step can hide make the step host-bound)."""
         self.tr = Transport(group, loopback=loopback)
         self.chunks = chunks
         self.group, self.P, self.rank = group, self.tr.P, self.tr.rank
@@ -84,11 +112,16 @@ class SlabResidual(object):
         self.dt, self.rho, self.nu, self.Lx, self.Ly = dt, rho, nu, Lx, Ly
         self.dx, self.dy = Lx / nx, Ly / ny
         self.compute = compute if compute is not None else HipCompute()
-        # the library's automatic pick (precise = True / 1) is made per pass; a sharded evaluation calls the passes one by one, so the
-        # decision is taken HERE, once, from both axes (all-float32 transforms only while nu pi N / (sqrt(3) L) <= 8 on both)
+        # the library's automatic pick (precise = True / 1) is made per pass; a sharded evaluation calls the passes one by one, so the decision is
+        # taken HERE, once, from both axes -- by the LIBRARY's own policy function (nns_spec_resolve_precise: all-float32 transforms only while
+        # nu pi N / (sqrt(3) L) <= 8 on both axes, NNS_SPEC_F64 honoured), so that the slab path and the single-process path cannot disagree
         if precise is True or (precise is not False and int(precise) == 1):
-            amp = max(abs(nu) * math.pi * n / (math.sqrt(3.) * abs(l)) for n, l in ((nx, Lx), (ny, Ly)))
-            precise = 0 if amp <= 8.0 else 2
+            resolve = getattr(self.compute, 'resolve_precise', None)
+            if resolve is not None:
+                precise = resolve(1, nu, nx, Lx, ny, Ly)
+            else:                                            # injected CPU stand-ins (tests): the same rule, stated here
+                amp = max(abs(nu) * math.pi * n / (math.sqrt(3.) * abs(l)) for n, l in ((nx, Lx), (ny, Ly)))
+                precise = 0 if amp <= 8.0 else 2
         self.precise = precise
         self._bufs = {}
 
@@ -101,15 +134,17 @@ class SlabResidual(object):
         return b
 
     # ------------------------------------------------------------------ FD: halo rows
+    def _halo_bufs(self, f0, F, tag):
+        B, nloc, ny = f0.shape
+        return tuple(self._buf((n, tag), (F, B, ny), f0) for n in ('first', 'last', 'top', 'bot'))
+
     def start_halo(self, fields, tag=0):
         """fields: list of F [B, nloc, ny] row slabs.  Packs their first / last rows (ONE launch each) and starts the ring
         exchange.  Returns (handle, top, bot): after handle.wait(), top / bot [F, B, ny] hold row -1 / row nloc of the slab
         (the periodic neighbours' edge rows).  tag: which set of message buffers to use (one per exchange in flight)."""
         f0 = fields[0]
         B, nloc, ny = f0.shape
-        F = len(fields)
-        first, last = self._buf(('first', tag), (F, B, ny), f0), self._buf(('last', tag), (F, B, ny), f0)
-        top, bot = self._buf(('top', tag), (F, B, ny), f0), self._buf(('bot', tag), (F, B, ny), f0)
+        first, last, top, bot = self._halo_bufs(f0, len(fields), tag)
         c = self.compute
         c.gather_lines(fields, first, B, nloc * ny, 0, ny)
         c.gather_lines(fields, last, B, nloc * ny, (nloc - 1) * ny, ny)
@@ -130,36 +165,45 @@ class SlabResidual(object):
     def _nchunks(self, B, chunks=None):
         c = chunks if chunks is not None else self.chunks
         if c is None:
-            # a stream-ordered transport overlaps chunk c+1's transfers with chunk c's kernels; a staged (blocking) one gains nothing
-            c = 2 if (self.tr.backend == 'nccl' and not self.tr.local) else 1
+            # ONE chunk unless asked: more chunks put the grouped halo send/recv and several asynchronous all-to-alls in flight on one process
+            # group at a time -- an interleaving that has run over gloo and as a one-rank RCCL loopback only (no two-GPU box in this pool), so it
+            # stays behind `chunks=` / `bench.py --chunks` until a multi-GPU run has confirmed it
+            c = 1
         return max(1, min(int(c), B))
 
-    def _pipeline(self, u, v, p, finish, chunks=None):
+    def _pipeline(self, u, v, p, finish, chunks=None, halo=False):
         """The spectral path's three stages, software-pipelined over chunks of the batch axis (independent grids):
 
-            stage 0 (chunk c):  pack row slabs -> send buffer [dest][u, v, p][Bc][nloc][ny/P];  start all-to-all #1
+            stage 0 (chunk c):  pack row slabs -> send buffer [dest][u, v, p][Bc][nloc][ny/P] (chunk 0, halo=True: the SAME launch also packs the two
+                                halo messages of the whole batch, and the ring exchange is posted next);  start all-to-all #1
             stage 1 (chunk c):  wait #1;  column pass on the receive buffer in place -> return buffer;  start all-to-all #2
-            stage 2 (chunk c):  wait #2;  scatter the returned blocks into row slabs;  finish(c, rows, partials)  [the row pass]
+            stage 2 (chunk c):  wait #2;  finish(c, rows, got): the row pass, reading its partials from the receive buffer `got`
+                                [src][P_u, P_v, P_d][Bc][nloc][ny/P] IN PLACE (round 4: no scatter copy between the collective and the row pass)
 
         enqueued in the order s0(c), s1(c-1), s2(c-2) per tick, so that on a stream-ordered transport (RCCL) the collectives run
         back to back on the communication stream -- #1(0), #1(1), #2(0), #1(2), #2(1), ... -- while the compute stream packs,
-        transforms and finishes other chunks: the links stay busy and all but the first pack / last row pass hide under them.
-        Every kernel treats grids independently, so the results do not depend on the chunking (checked bitwise in the tests).
-        finish(c, sl, parts): sl = the chunk's batch slice, parts = its three partial fields as row slabs."""
+        transforms and finishes other chunks.  Per chunk: 1 copy kernel + 2 collectives + 2 compute kernels (round 3: 2 copy kernels,
+        and 2 more launches per step for the halo messages).  Every kernel treats grids independently, so the results do not depend on
+        the chunking (checked bitwise in the tests).  Returns the halo (handle, top, bot) or None."""
         B, nloc, ny = u.shape
         P, nyl, c_ = self.P, self.nyloc, self.compute
         C = self._nchunks(B, chunks)
         bounds = [(B * c // C, B * (c + 1) // C) for c in range(C)]
         st = [None] * C
-        parts_full = [torch.empty_like(u) for _ in range(3)]
+        fields = [u, v, p]
+        hal = [None]
 
         def s0(c):
-            sl = slice(*bounds[c])
-            f = [t[sl] for t in (u, v, p)]
-            shape = (P, 3, f[0].shape[0], nloc, nyl)
+            g0, g1 = bounds[c]
+            shape = (P, 3, g1 - g0, nloc, nyl)
             send, recv = self._buf(('a2a_s1', c), shape, u), self._buf(('a2a_r1', c), shape, u)
-            c_.transpose_pack(f, send, P)
-            st[c] = dict(sl=sl, shape=shape, recv=recv, h1=self.tr.all_to_all(recv, send))
+            if c == 0 and halo:
+                first, last, top, bot = self._halo_bufs(u, 3, 0)
+                c_.pack_halo(fields, send, first, last, g0, P)
+                hal[0] = (self.tr.ring_exchange(first, last, bot, top, wrap=True), top, bot)
+            else:
+                c_.pack_halo(fields, send, None, None, g0, P)
+            st[c] = dict(sl=slice(g0, g1), shape=shape, recv=recv, h1=self.tr.all_to_all(recv, send))
 
         def s1(c):
             d = st[c]
@@ -171,9 +215,7 @@ class SlabResidual(object):
         def s2(c):
             d = st[c]
             d['h2'].wait()
-            parts = [t[d['sl']] for t in parts_full]
-            c_.transpose_unpack(d['got'], parts, P)
-            finish(c, d['sl'], parts)
+            finish(c, d['sl'], d['got'], hal[0])
 
         for tick in range(C + 2):
             if tick < C:
@@ -182,39 +224,36 @@ class SlabResidual(object):
                 s1(tick - 1)
             if 0 <= tick - 2 < C:
                 s2(tick - 2)
-        return parts_full
-
-    def _xpass_partials(self, u, v, p, chunks=None):
-        """Row slabs u, v, p -> the column pass's three partials as row slabs (2 all-to-alls, 2 copy kernels per chunk)."""
-        return self._pipeline(u, v, p, lambda c, sl, parts: None, chunks)
+        return hal[0]
 
     def spectral(self, u, v, p, u_prev, v_prev, chunks=None):
         c_ = self.compute
-        fin = lambda c, sl, parts: c_.spec_ypass(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], *parts, self.dt, self.Ly, self.rho, self.nu, self.precise)
-        return tuple(self._pipeline(u, v, p, fin, chunks))
+        out = tuple(torch.empty_like(u) for _ in range(3))
+
+        def fin(c, sl, got, hal):
+            c_.spec_ypass_seg(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], got, tuple(t[sl] for t in out), self.dt, self.Ly, self.rho, self.nu, self.precise)
+        self._pipeline(u, v, p, fin, chunks)
+        return out
 
     def both(self, u, v, p, u_prev, v_prev, stencil=5, chunks=None):
-        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- the halo exchange travels under the
-        transposes and the column pass of the first batch chunk, then ONE row pass per chunk does the stencil and finishes the spectral
-        residual; the chunks are pipelined (`_pipeline`)."""
+        """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- the halo messages are packed by the first
+        chunk's pack launch and travel under the two transposes and the column pass, then ONE row pass per chunk does the stencil and finishes
+        the spectral residual, reading the returned partials where the all-to-all put them; the chunks are pipelined (`_pipeline`)."""
         if stencil != 5 or u.dtype not in getattr(self.compute, 'fused_dtypes', (torch.float32,)):
             return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev, chunks)
-        B = u.shape[0]
-        C = self._nchunks(B, chunks)
-        # ONE halo exchange for the whole batch leaves first (two pack launches, one grouped send/recv): tiny, and the first row pass needs it
-        # two ticks later; every chunk's row pass reads its grids out of the same two messages (halo_grid0)
-        h, top, bot = self.start_halo([u, v, p])
         out_fd = tuple(torch.empty_like(u) for _ in range(3))
+        out_sp = tuple(torch.empty_like(u) for _ in range(3))
         waited = []
 
-        def fin(c, sl, parts):
+        def fin(c, sl, got, hal):
+            h, top, bot = hal
             if not waited:
                 h.wait()
                 waited.append(True)
-            self.compute.both_rowpass_halo(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], top, bot, parts, self.dt, self.dx, self.Ly, self.rho, self.nu,
-                                           self.precise, out_fd=tuple(t[sl] for t in out_fd), halo_grid0=sl.start)
-        parts = self._pipeline(u, v, p, fin, C)
-        return out_fd, tuple(parts)
+            self.compute.both_rowpass_halo_seg(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], top, bot, got, self.dt, self.dx, self.Ly, self.rho, self.nu,
+                                               self.precise, tuple(t[sl] for t in out_fd), tuple(t[sl] for t in out_sp), halo_grid0=sl.start)
+        self._pipeline(u, v, p, fin, chunks, halo=True)
+        return out_fd, out_sp
 
 
 class HipSorCompute(object):

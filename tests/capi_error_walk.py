@@ -45,7 +45,7 @@ for base, args in _lib._DUAL.items():
     names[base + '_f32'] = args
     names[base + '_f64'] = args
 queries = ('nns_version', 'nns_last_error', 'nns_device_info', 'nns_ode_mlp_bwd_workspace', 'nns_fd_predictor_adi_workspace', 'nns_fd_sor_workspace',
-           'nns_fd_sor_redblack_workspace')
+           'nns_fd_sor_redblack_workspace', 'nns_spec_resolve_precise')
 for name, argtypes in sorted(names.items()):
     if name in queries:
         continue
@@ -54,6 +54,8 @@ for name, argtypes in sorted(names.items()):
 for q in ('nns_ode_mlp_bwd_workspace', 'nns_fd_predictor_adi_workspace', 'nns_fd_sor_workspace', 'nns_fd_sor_redblack_workspace'):
     assert getattr(L, q)(*zero_args(names[q])) == 0, q              # size queries answer 0 for nonsense
 assert L.nns_version() >= 1
+assert L.nns_spec_resolve_precise(1, 6.283e-3, 1024, 6.283, 1024, 6.283) == 0 and L.nns_spec_resolve_precise(1, 1.0, 1024, 6.283, 1024, 6.283) == 2     # a policy query
+assert L.nns_spec_resolve_precise(0, 1.0, 1024, 6.283, 64, 6.283) == 0 and L.nns_spec_resolve_precise(2, 1e-3, 64, 6.283, 64, 6.283) == 2
 rc = L.nns_device_info(None, 0, None, None)
 assert rc in (OK, LAUNCH)                                            # LAUNCH without a device: the HIP error string is reported
 if rc == LAUNCH:
@@ -70,6 +72,13 @@ expect('rowpass_halo without halos', L.nns_residual_both_rowpass_halo_f32(P, P, 
 expect('rowpass_halo short halo stride', L.nns_residual_both_rowpass_halo_f32(*([P] * 13), 2, 8, 64, 64, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), INVALID)
 expect('xpass_seg seg_rows=3', L.nns_spec_residual_xpass_seg_f32(P, P, P, P, P, P, 1, 64, 8, 3, 1000, 6.28, 1.0, 0.01, 1, None), INVALID)
 expect('xpass_seg short stride', L.nns_spec_residual_xpass_seg_f32(P, P, P, P, P, P, 1, 64, 8, 16, 4, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('ypass_seg seg_cols=24', L.nns_spec_residual_ypass_seg_f32(*([P] * 8), 24, 100000, P, P, P, 1, 8, 64, 1e-3, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('ypass_seg seg_cols < ny / 16', L.nns_spec_residual_ypass_seg_f32(*([P] * 8), 2, 100000, P, P, P, 1, 8, 64, 1e-3, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('ypass_seg short stride', L.nns_spec_residual_ypass_seg_f32(*([P] * 8), 16, 100, P, P, P, 1, 8, 64, 1e-3, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('ypass_seg ny=96', L.nns_spec_residual_ypass_seg_f32(*([P] * 8), 32, 100000, P, P, P, 1, 8, 96, 1e-3, 6.28, 1.0, 0.01, 1, None), UNSUPPORTED)
+expect('rowpass_halo_seg no partials', L.nns_residual_both_rowpass_halo_seg_f32(*([P] * 7), None, P, P, 16, 100000, *([P] * 6), 1, 8, 64, 0, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('rowpass_halo_seg no halo', L.nns_residual_both_rowpass_halo_seg_f32(*([P] * 5), None, None, P, P, P, 16, 100000, *([P] * 6), 1, 8, 64, 0, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), INVALID)
+expect('rowpass_halo_seg huge block', L.nns_residual_both_rowpass_halo_seg_f32(*([P] * 10), 1024, 1 << 40, *([P] * 6), 4096, 1024, 1024, 0, 1e-3, 0.1, 6.28, 1.0, 0.01, 1, None), UNSUPPORTED)
 expect('fd_residual stencil=7', L.nns_fd_residual_f32(P, P, P, P, P, P, P, P, 1, 8, 8, 1e-3, 0.1, 0.1, 1.0, 0.01, 7, None), INVALID)
 expect('fd_residual_halo rows', L.nns_fd_residual_halo_f64(P, P, P, P, P, P, P, P, P, P, 1, 8, 8, 5, 20, 1e-3, 0.1, 0.1, 1.0, 0.01, 5, None), INVALID)
 expect('fd_residual_halo no halo', L.nns_fd_residual_halo_f32(P, P, P, P, P, None, None, P, P, P, 1, 8, 8, 0, 8, 1e-3, 0.1, 0.1, 1.0, 0.01, 5, None), INVALID)
@@ -100,6 +109,9 @@ expect('slab gather nfields=5', L.nns_slab_gather_lines_f32(ptrs5, 5, P, 1, 0, 0
 ptrs2 = (C.c_void_p * 2)(P, None)
 expect('slab gather NULL field', L.nns_slab_gather_lines_f64(ptrs2, 2, P, 1, 0, 0, 8, 1, None), INVALID)
 expect('slab transpose ny % P', L.nns_slab_transpose_pack_f32(ptrs5, 3, P, 1, 4, 10, 4, None), INVALID)
+expect('slab pack_halo g0 + Bc > B', L.nns_slab_pack_halo_f32(ptrs5, 3, P, P, P, 4, 3, 2, 8, 64, 4, None), INVALID)
+expect('slab pack_halo one halo buffer', L.nns_slab_pack_halo_f64(ptrs5, 3, P, P, None, 4, 0, 2, 8, 64, 4, None), INVALID)
+expect('slab pack_halo ny / P not a vector multiple', L.nns_slab_pack_halo_f32(ptrs5, 3, P, None, None, 4, 0, 2, 8, 12, 4, None), UNSUPPORTED)
 expect('coarsen agg', L.nns_coarsen_f32(P, P, P, P, P, P, 2, 8, 8, 3, 3, 2, None), (INVALID, UNSUPPORTED))
 expect('cheb_gemm M=0', L.nns_cheb_gemm_f64(P, 4, 0, P, 4, 0, P, 4, 0, 4, 4, 1.0, 0.0, 1, None), (INVALID, UNSUPPORTED))
 expect('rfft2 nx=48', L.nns_spec_rfft2_f32(P, P, 1, 48, 64, None), (INVALID, UNSUPPORTED))

@@ -43,6 +43,33 @@ class OracleCompute(OracleLines):
                 t[:, :, s * nyl:(s + 1) * nyl].copy_(recv[s, f])
         return fields
 
+    def pack_halo(self, fields, send, first, last, g0, P):
+        """The fused pack + halo launch of HipCompute (nns_slab_pack_halo_*): grids [g0, g0 + Bc) into the send buffer, the edge rows of ALL grids
+        into the two halo messages."""
+        self.transpose_pack([t[g0:g0 + send.shape[2]] for t in fields], send, P)
+        if first is not None:
+            for f, t in enumerate(fields):
+                first[f].copy_(t[:, 0]); last[f].copy_(t[:, -1])
+        return send
+
+    @staticmethod
+    def _rows_of(got):
+        """[src][3][B][nloc][nyl] (the return all-to-all's receive buffer) -> the three partial fields as row slabs [B][nloc][P * nyl]: what the
+        segmented row passes read in place."""
+        P, _, B, nloc, nyl = got.shape
+        return [got[:, f].permute(1, 2, 0, 3).reshape(B, nloc, P * nyl).clone() for f in range(3)]
+
+    def spec_ypass_seg(self, u, v, p, up, vp, got, out, dt, Ly, rho, nu, precise):
+        r = OP.spectral_ypart(*[t.numpy() for t in (u, v, p, up, vp)], *[t.numpy() for t in self._rows_of(got)], dt, Ly, rho, nu)
+        for o, a in zip(out, r):
+            o.copy_(_t(a))
+        return out
+
+    def both_rowpass_halo_seg(self, u, v, p, up, vp, top, bot, got, dt, dx, Ly, rho, nu, precise, out_fd, out_spec, halo_grid0=0):
+        g = slice(halo_grid0, halo_grid0 + u.shape[0])               # this call's grids of the whole-batch halo messages
+        self.fd_residual_halo(u, v, p, up, vp, top[:, g], bot[:, g], dt, dx, Ly / u.shape[2], rho, nu, 5, None, out_fd)
+        return out_fd, self.spec_ypass_seg(u, v, p, up, vp, got, out_spec, dt, Ly, rho, nu, precise)
+
     def fd_residual_halo(self, u, v, p, up, vp, top, bot, dt, dx, dy, rho, nu, stencil, rows, out):
         pad = lambda f, k: np.concatenate([top[k].numpy()[:, None, :], f.numpy(), bot[k].numpy()[:, None, :]], axis=1)
         same = lambda f: np.concatenate([f.numpy()[:, :1], f.numpy(), f.numpy()[:, -1:]], axis=1)      # halo values of *_prev are never used

@@ -623,3 +623,78 @@ def test_slab_transpose_pack_unpack_kernels(B, nloc, ny, P, dtype, gpu_device):
     ops.slab_transpose_unpack(send, back, P)
     for a, b in zip(back, fields):
         assert torch.equal(a, b)
+
+
+def _to_seg(parts, P):
+    """Row-slab partials [B, nloc, ny] x 3 -> the return all-to-all's receive layout [P][3][B][nloc][ny / P]."""
+    nyl = parts[0].shape[2] // P
+    return torch.stack([torch.stack([t[:, :, s * nyl:(s + 1) * nyl] for t in parts]) for s in range(P)]).contiguous()
+
+
+@pytest.mark.parametrize('ny,P,B', [(1024, 8, 5), (1024, 8, 800), (1024, 2, 5), (1024, 16, 5), (256, 4, 5), (256, 4, 3000), (64, 16, 5), (128, 1, 5)])
+@pytest.mark.parametrize('precise', [0, 2])
+def test_row_passes_read_segmented_partials_in_place(ny, P, B, precise, gpu_device):
+    """Round 4: the slab step's row passes read the column-pass partials where the return all-to-all delivers them -- [src][field][grid][row]
+    [ny / P] -- instead of from a copy scattered into row slabs.  Fused (marching / float64-forward) and plain spectral row pass, every
+    piece length the layout admits (ny / P from the whole row down to one lane group, ny / 16), one-row chunks (B = 5) and marching chunks of
+    several rows with a ragged last one (B = 800 / 3000 x nloc = 11), a halo message shared by a larger batch: BITWISE the in-place forms."""
+    from nns import ops
+    nloc = 11
+    d = _rough_fields(B, nloc, ny, seed=ny + P)
+    g = torch.Generator(device='cuda'); g.manual_seed(7)
+    parts = [torch.randn(B, nloc, ny, device='cuda', generator=g) for _ in range(3)]
+    Bh, g0 = B + 3, 2                                                        # the halo messages cover a larger batch: this call is grids 2 .. 6 of it
+    top = torch.randn(3, Bh, ny, device='cuda', generator=g)
+    bot = torch.randn(3, Bh, ny, device='cuda', generator=g)
+    got = _to_seg(parts, P)
+    ref_parts = [t.clone() for t in parts]
+    ref_fd, ref_sp = ops.residual_both_rowpass_halo(*d, top, bot, ref_parts, DT, L / 1024, L, RHO, NU, precise=precise, halo_grid0=g0)
+    fd, sp = ops.residual_both_rowpass_halo_seg(*d, top, bot, got, DT, L / 1024, L, RHO, NU, precise=precise, halo_grid0=g0)
+    for a, b in zip(list(fd) + list(sp), list(ref_fd) + list(ref_sp)):
+        assert torch.equal(a, b)
+    ref_y = ops.spec_residual_ypass_(*d, *[t.clone() for t in parts], DT, L, RHO, NU, precise=precise)
+    y = ops.spec_residual_ypass_seg(*d, got, DT, L, RHO, NU, precise=precise)
+    for a, b in zip(y, ref_y):
+        assert torch.equal(a, b)
+    assert torch.equal(got, _to_seg(parts, P))                                # the receive buffer is read only
+
+
+def test_segmented_row_pass_refuses_what_it_cannot_address(gpu_device):
+    from nns import ops, _lib
+    d = _rough_fields(2, 8, 256, seed=1)
+    top = bot = torch.zeros(3, 2, 256, device='cuda')
+    with pytest.raises(_lib.NnsError, match='seg_cols'):                       # 32 ranks: pieces of 8 columns < one lane group of 16
+        ops.residual_both_rowpass_halo_seg(*d, top, bot, torch.zeros(32, 3, 2, 8, 8, device='cuda'), DT, 0.1, L, RHO, NU)
+    d96 = _rough_fields(2, 8, 96, seed=1)
+    with pytest.raises(_lib.NnsError, match='power of two'):
+        ops.spec_residual_ypass_seg(*d96, torch.zeros(2, 3, 2, 8, 48, device='cuda'), DT, L, RHO, NU)
+
+
+@pytest.mark.parametrize('B,nloc,ny,P,dtype,g0,Bc', [(5, 6, 64, 4, torch.float32, 1, 3), (2, 3, 16, 2, torch.float64, 0, 2), (64, 16, 1024, 8, torch.float32, 32, 32),
+                                                       (3, 4, 32, 8, torch.float32, 0, 1)])
+def test_slab_pack_halo_one_launch(B, nloc, ny, P, dtype, g0, Bc, gpu_device):
+    """The fused pack + halo launch (nns_slab_pack_halo_*): a batch chunk into the all-to-all send buffer and the edge rows of the WHOLE batch
+    into the two halo messages, against the separate pack / gather kernels; without halo buffers only the pack; HipCompute.pack_halo's
+    fallback (ny / P not a vector multiple) gives the same."""
+    from nns import ops
+    from nns.slab import HipCompute
+    g = torch.Generator(device='cuda'); g.manual_seed(B + ny)
+    fields = [torch.randn(B, nloc, ny, device='cuda', dtype=dtype, generator=g) for _ in range(3)]
+    nyl = ny // P
+    want = torch.empty(P, 3, Bc, nloc, nyl, device='cuda', dtype=dtype)
+    ops.slab_transpose_pack([t[g0:g0 + Bc].contiguous() for t in fields], want, P)
+    wf = torch.stack([t[:, 0] for t in fields]).contiguous(); wl = torch.stack([t[:, -1] for t in fields]).contiguous()
+    for use_compute in (False, True):
+        send = torch.zeros_like(want); first = torch.zeros(3, B, ny, device='cuda', dtype=dtype); last = torch.zeros_like(first)
+        (HipCompute().pack_halo if use_compute else ops.slab_pack_halo)(fields, send, first, last, g0, P)
+        assert torch.equal(send, want) and torch.equal(first, wf) and torch.equal(last, wl)
+        send.zero_()
+        (HipCompute().pack_halo if use_compute else ops.slab_pack_halo)(fields, send, None, None, g0, P)
+        assert torch.equal(send, want)
+    odd = [t[:, :, :24].contiguous() for t in fields] if ny >= 32 else None
+    if odd is not None and dtype == torch.float32:                              # ny / P = 6: the separate kernels behind the same call
+        send = torch.zeros(4, 3, Bc, nloc, 6, device='cuda', dtype=dtype); first = torch.zeros(3, B, 24, device='cuda', dtype=dtype); last = torch.zeros_like(first)
+        HipCompute().pack_halo(odd, send, first, last, g0, 4)
+        w2 = torch.empty_like(send)
+        ops.slab_transpose_pack([t[g0:g0 + Bc].contiguous() for t in odd], w2, 4)
+        assert torch.equal(send, w2) and torch.equal(first, torch.stack([t[:, 0] for t in odd])) and torch.equal(last, torch.stack([t[:, -1] for t in odd]))

@@ -16,6 +16,7 @@ root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 
 def short(k):
+    k = k.replace('(anonymous namespace)::', '').replace('void ', '')
     k = k.split('(')[0]
     return k if len(k) < 90 else k[:87] + '...'
 

@@ -7,7 +7,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 
 extra = [a for a in sys.argv[2:] if a.startswith('-')]
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'neural-navier-stokes_amd', 'csrc')
 exact = ['-ffp-contract=off'] if src.split('.')[0] in ('fd_kernels', 'sor_kernels', 'cheb_kernels', 'coarsen_kernels') else []
-noslp = ['-fno-slp-vectorize'] if src.startswith('spectral_k') or src.startswith('spectral_b') else []
+noslp = ['-fno-slp-vectorize'] if src.startswith(('spectral_k', 'spectral_b', 'spectral_s')) else []
 cmd = ['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fvisibility=hidden', '-Rpass-analysis=kernel-resource-usage',
        '-c', os.path.join(csrc, src), '-o', '/dev/null'] + exact + noslp + extra
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
