@@ -346,8 +346,11 @@ def main():
         f = [t[:, rank * nloc:(rank + 1) * nloc].contiguous() for t in f]          # this rank's rows of every grid
         sl = SlabResidual(n, n, dt, rho, nu, L, L, precise=prec, chunks=args.chunks, loopback=args.loopback)
 
-        def step():           # per batch chunk: halo exchange under the two transposes + column pass, then ONE fused row pass (5-point stencil)
-            sl.both(*f, stencil=args.stencil)
+        s_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
+        s_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
+
+        def step():           # per batch chunk: pack (+ halo rows), all-to-all, column pass, all-to-all, ONE fused row pass (5-point stencil) on the receive buffer
+            sl.both(*f, stencil=args.stencil, out_fd=s_fd, out_spec=s_sp)
     else:
         out_fd = tuple(torch.empty_like(f[0]) for _ in range(3))
         out_sp = tuple(torch.empty_like(f[0]) for _ in range(3))
@@ -364,6 +367,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    if dist is not None:
+        sync_all()               # (the first barriers of a process group can take tens of ms: two before the clock starts)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -421,17 +426,17 @@ def main():
             # run has confirmed the interleaving (the headline runs --chunks, default 1)
             if sl._nchunks(B) == 1 and B >= 2:
                 for _ in range(min(args.warmup, 5)):
-                    sl.both(*f, stencil=args.stencil, chunks=2)
+                    sl.both(*f, stencil=args.stencil, chunks=2, out_fd=s_fd, out_spec=s_sp)
                 sync_all()
                 tp0 = time.perf_counter()
                 for _ in range(args.steps):
-                    sl.both(*f, stencil=args.stencil, chunks=2)
+                    sl.both(*f, stencil=args.stencil, chunks=2, out_fd=s_fd, out_spec=s_sp)
                 sync_all()
                 tpp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
                 dist.all_reduce(tpp, op=dist.ReduceOp.MAX)
                 th0 = time.perf_counter()
                 for _ in range(10):
-                    sl.both(*f, stencil=args.stencil, chunks=2)
+                    sl.both(*f, stencil=args.stencil, chunks=2, out_fd=s_fd, out_spec=s_sp)
                 hp = 1e3 * (time.perf_counter() - th0) / 10
                 torch.cuda.synchronize()
                 multi['pipelined'] = dict(chunks=2, value=pts * args.steps / float(tpp.item()), ms_per_step=1e3 * float(tpp.item()) / args.steps,

@@ -345,6 +345,10 @@ int nns_residual_both_rowpass_halo_seg_f32(const float* u, const float* v, const
  * forward transforms), from both transformed axes and the NNS_SPEC_F64 override -- the one policy implementation, for hosts that call the
  * passes one by one (nns/slab.py). */
 int nns_spec_resolve_precise(int precise, double nu, int nx, double Lx, int ny, double Ly);
+/* Axis lengths outside the FFT engine's sizes run on circulant matrices (AXIS LENGTHS note above) whose table of (n, L) is built on the host,
+ * allocated and copied SYNCHRONOUSLY at the first call that needs it, once per device -- not possible while a stream is being captured into a HIP
+ * graph (such a call returns NNS_ERR_UNSUPPORTED).  This builds the table of one axis ahead of time on the current device. */
+int nns_spec_dense_warmup(int n, double L);
 /* Spectral derivatives of ONE real field (d/dx <-> i kx with the Nyquist mode dropped, lap <-> -|k|^2; definition
  * oracle/periodic.py: spectral_derivs): any of f_x, f_y, f_lap may be NULL.  precise as above. */
 int nns_spec_derivs_f32(const float* f, float* f_x, float* f_y, float* f_lap, int batch, int nx, int ny,

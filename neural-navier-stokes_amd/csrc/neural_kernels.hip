@@ -1008,8 +1008,21 @@ constexpr int kMfNPT = 4;                                   // pixel tiles (of 1
 #define NNS_MF_ATTR
 #endif
 constexpr int kMfTCMax = 176;                               // time rows per chunk at most (11 blocks of 16)
-constexpr int kMfCwLd = 20;                                 // LDS row stride (floats) of the coefficient block and of the 16 x 16 tiles: with 20 both access
-                                                            // patterns of a tile -- [4 lg + r][lj] and [lj][4 s + lg] -- touch 64 distinct banks
+#ifndef NNS_MF_SWZ
+#define NNS_MF_SWZ 0               // 1: the 16 x 16 tiles (coefficient blocks, the transposing tile) are XOR-swizzled, 0: rows padded to 20 floats (rounds 2-3)
+#endif
+// A 16 x 16 float tile is touched two ways: an instruction covers rows {r, 4 + r, 8 + r, 12 + r} x all columns ([4 lg + r][lj]), or all rows x
+// columns {4 s .. 4 s + 3} ([lj][4 s + lg]).  ds_read/write_b32 serve a wave as two 32-lane halves on 32 banks.  Padded to 20 floats per row the
+// first pattern is conflict-free, but in the second rows lj and lj + 8 are 160 floats = 5 x 32 banks apart: every such read takes two passes
+// (26-29 % of the kernel's LDS cycles are bank conflicts: profiles/r03_mfma_pmc_final.csv).  Round 4 built the conflict-free form VERDICT r3 asked
+// for -- no padding, element (t, p) at 16 (t ^ ((t >> 2) & 1)) + (p ^ (t & 14)): a half of the first pattern (rows r, 4 + r) lands in two row
+// slots of opposite parity = the two 16-bank halves; a half of the second (16 rows x 2 columns) finds, inside each parity class, 8 rows whose XOR
+// keys differ in bits 1..3 -- and MEASURED it (profiles/r04_ab_c5_swizzle.txt, same box, three rounds): conflicts 29 % -> 1.6 % of LDS-active
+// cycles, LDS-active cycles 2.13e8 -> 1.53e8 per launch, sweep 1.690 -> 1.713 ms.  The LDS was never the limit (24 % busy): the sweep is bound by
+// the issue of its 44 dependent float32 MFMAs per 4 KB (matrix pipe 0.60 busy, 58 % of wave-cycles stalled at issue), and the swizzle's index
+// arithmetic costs what the shorter reads save.  Kept behind the macro, off.
+__device__ __forceinline__ int mf_tile(int t, int p) { return NNS_MF_SWZ ? 16 * (t ^ ((t >> 2) & 1)) + (p ^ (t & 14)) : t * 20 + p; }
+constexpr int kMfCwLd = NNS_MF_SWZ ? 16 : 20;               // floats per tile row
 // MODE as in basis_loss_pk_kernel: 1 = gradients of scale * (pred - obs), 2 = gradients for the upstream gradient passed as `obs`
 // (no prediction), 3 = sum of squares AND the unscaled gradients.
 template <int KQ, int MODE>
@@ -1056,7 +1069,7 @@ __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const 
     // every pixel strip starts at its own chunk and wraps around, so that the bursts of gcoeff atomics at the chunk ends go to
     // different rows.  The next chunk's coefficients are requested into registers when a chunk starts and written to LDS between
     // the two barriers at its end; the observation prefetch runs across the chunk boundaries.
-    constexpr int LDG = KQ <= 3 ? 12 : LD;                                        // row stride of the parked gcoeff tiles (K <= 12: only 12 columns are kept)
+    constexpr int LDG = KQ <= 3 ? 12 : 20;                                        // row stride of the parked gcoeff tiles (K <= 12: only 12 columns are kept)
     constexpr int KM = 4 * KQ;                                                    // coefficient columns that can be non-zero
     constexpr int CNR = (kMfTCMax * KM + 255) / 256;
     const int nchunks = (t_hi - t_lo + TC - 1) / TC;
@@ -1075,7 +1088,7 @@ __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const 
 #pragma unroll
         for (int q = 0; q < CNR; ++q) {
             const int e = tid + 256 * q, tt = e / KM, k = e % KM;
-            if (tt < TC) cw[tt * LD + k] = cn[q];
+            if (tt < TC) cw[(tt >> 4) * (16 * LD) + mf_tile(tt & 15, k)] = cn[q];
         }
     };
     float4 on[4];                                                                 // row r of the NEXT block: this lane's four consecutive pixels = its four tiles
@@ -1109,9 +1122,9 @@ __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const 
             if (b + 1 < nb) request(t0, b + 1); else request(t0n, more ? 0 : b);    // the next block is in flight while this one is multiplied
             float Aw[KQ], AwT[4], rm[4];
 #pragma unroll
-            for (int s = 0; s < KQ; ++s) Aw[s] = cw[(tb + lj) * LD + 4 * s + lg];
+            for (int s = 0; s < KQ; ++s) Aw[s] = cw[tb * LD + mf_tile(lj, 4 * s + lg)];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { AwT[s] = cw[(tb + 4 * lg + s) * LD + lj]; rm[s] = tb + 4 * lg + s < tn ? 1.f : 0.f; }
+            for (int s = 0; s < 4; ++s) { AwT[s] = cw[tb * LD + mf_tile(4 * lg + s, lj)]; rm[s] = tb + 4 * lg + s < tn ? 1.f : 0.f; }
             f32x4 gc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
@@ -1143,12 +1156,12 @@ __global__ __launch_bounds__(256) NNS_MF_ATTR void basis_loss_mfma_kernel(const 
                 if (NNS_MF_EXP == 2) continue;
                 // gcoeff: g with t on the lanes, through the transposing tile (rows = t, columns = pix)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gt[(4 * lg + r) * LD + lj] = g[r];
+                for (int r = 0; r < 4; ++r) gt[mf_tile(4 * lg + r, lj)] = g[r];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 float gA[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) gA[s] = gt[lj * LD + 4 * s + lg];
+                for (int s = 0; s < 4; ++s) gA[s] = gt[mf_tile(lj, 4 * s + lg)];
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1471,7 +1484,7 @@ int launch_loss_mfma(const float* coeff, const float* basis, const float* obs, d
     // transposing tiles must leave room for 3 workgroups per CU (the register budget's occupancy)
     const int tcmax = K <= 12 ? kMfTCMax : 112;
     const int TC = rps < tcmax ? rps : tcmax;
-    const int ldg = K <= 12 ? 12 : kMfCwLd;
+    const int ldg = K <= 12 ? 12 : 20;
     const size_t lds = ((size_t)TC * kMfCwLd + 4 * 16 * kMfCwLd + (size_t)(TC / 16) * 4 * 16 * ldg) * sizeof(float);
     hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), s);
     if (e == hipSuccess && ns > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), s);

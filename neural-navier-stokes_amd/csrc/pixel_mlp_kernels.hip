@@ -623,6 +623,12 @@ constexpr int kBwdDepth = NNS_PMB_DEPTH;
 #define NNS_PMB_ALT 0              // 1: the data chain's MFMAs alternate between the two accumulators
 #endif
 constexpr bool kBwdAlt = NNS_PMB_ALT != 0;
+#ifndef NNS_PMB_OVERLAP
+#define NNS_PMB_OVERLAP 0          // bit 0 (forward recompute) / bit 1 (backward walk): the chain waves convert the FIRST output tile's accumulators (mask / pack,
+                                   // 4 - 8 vector instructions per MFMA gap) under the MFMAs of the second tile instead of after the layer's last MFMA (OT = 2 only).
+                                   // Round 4, same-box A/B (profiles/r04_ab_pixel_mlp_bwd.log): both 0.96 -> 1.04 ms -- the gap's issue slots are taken (2 LDS reads,
+                                   // a store pair and the MFMA's own 8 cycles), the conversion only stretches the MFMA loop
+#endif
 #ifndef NNS_PMB_EXP
 #define NNS_PMB_EXP 0              // timing probes of the split backward (wrong results): 1 = chain waves read no weight fragments from LDS, 2 = no per-layer barriers, 3 = no weight-gradient MFMAs,
                                    // 4 = gradient waves only keep the barriers, 5 = no forward recompute, 6 = no image writes, 7 = no ReLU' mask
@@ -830,6 +836,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 const unsigned char* wnext = lds + (l + 2 < nl ? l + 1 : l) * U::W_BYTES;          // the next recomputed layer's image (clamped)
                 f32x16 (&acc)[OT] = accb[l & 1];                                                   // holds this layer's bias already
                 f32x16 (&accn)[OT] = accb[(l + 1) & 1];
+                i32x4v cv[2];                                                                      // NNS_PMB_OVERLAP: tile 0's two fragments, converted under tile 1's MFMAs
                 static_for<0, NM>([&](auto ic) {
                     constexpr int idx = decltype(ic)::value, ot = idx / SS, s2 = idx % SS, nx = idx + D;
                     acc[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PMB(1) ? afrag[l][(s2 + 1) % SS] : wr[idx % D], afrag[l][s2], acc[ot], 0, 0, 0);
@@ -837,6 +844,13 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     else wr[idx % D] = frag_w<OT>(wnext, r, h, (nx - NM) / SS, (nx - NM) % SS);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                              // a frag_w is one ds_read2_b64
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr ((NNS_PMB_OVERLAP & 1) && OT == 2 && idx >= SS && !PMB(8)) {
+                        // tile 0's accumulator is complete: a quarter of its conversion per MFMA of tile 1 (fragment (idx - SS) >> 1, its ints 2 q, 2 q + 1)
+                        constexpr int pc = idx - SS, fs = pc >> 1, q = pc & 1;
+                        cv[fs][2 * q] = pack2<true>(acc[0][8 * fs + 4 * q], acc[0][8 * fs + 4 * q + 1]);
+                        cv[fs][2 * q + 1] = pack2<true>(acc[0][8 * fs + 4 * q + 2], acc[0][8 * fs + 4 * q + 3]);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
                 });
                 {   // the next layer's bias, requested under this layer's conversion (a read placed at its use is the youngest in the queue: lgkmcnt(0))
                     const float* bn = reinterpret_cast<const float*>(bias0 + (l + 2 < nl ? l + 1 : l) * U::B_BYTES);
@@ -847,7 +861,10 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     __builtin_amdgcn_sched_group_barrier(0x100, 4 * OT, 0);
                 }
 #pragma unroll
-                for (int s = 0; s < SS; ++s) afrag[l + 1][s] = PMB(8) ? raw8(acc[s >> 1], 8 * (s & 1)) : pack8<true>(acc[s >> 1], 8 * (s & 1));
+                for (int s = 0; s < SS; ++s) {
+                    if ((NNS_PMB_OVERLAP & 1) && OT == 2 && !PMB(8) && s < 2) afrag[l + 1][s] = __builtin_bit_cast(bf16x8, cv[s]);
+                    else afrag[l + 1][s] = PMB(8) ? raw8(acc[s >> 1], 8 * (s & 1)) : pack8<true>(acc[s >> 1], 8 * (s & 1));
+                }
             }
         }
 #if NNS_PMB_TIMING
@@ -898,6 +915,8 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                 unsigned char* imgD = img0 + (l & 1) * 2 * U::IMG_BYTES;
                 unsigned char* rowD = imgD + img_row_lane<OT>(wave, r, h);
                 unsigned char* rowA = rowD + U::IMG_BYTES;
+                i32x4v dn[2];                                                                      // NNS_PMB_OVERLAP: the next delta's first two fragments (from nd[0])
+                constexpr bool kOvl = (NNS_PMB_OVERLAP & 2) && OT == 2 && !kBwdAlt && !PMB(7) && !PMB(9);
                 static_for<0, NM>([&](auto ic) {
                     constexpr int idx = decltype(ic)::value, it = kBwdAlt ? idx % OT : idx / SS, s2 = kBwdAlt ? idx / OT : idx % SS, nx = idx + D;
                     constexpr int nit = kBwdAlt ? nx % OT : (nx % NM) / SS, ns2 = kBwdAlt ? (nx % NM) / OT : nx % SS;
@@ -916,12 +935,26 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     if (!PMB(6)) __builtin_amdgcn_sched_group_barrier(0x200, per, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (kOvl && idx >= SS) {
+                        // nd[0] is complete: a quarter of its mask / pack step per MFMA of nd[1] (the old delta fragments are still operands and
+                        // image rows of this layer: the new ones go to registers of their own)
+                        if (l > 0) {
+                            constexpr int pc = idx - SS, fs = pc >> 1, q = pc & 1;
+                            const i32x4v m = __builtin_bit_cast(i32x4v, afrag[l][fs]);
+                            dn[fs][2 * q] = mask2(pack2<false>(nd[0][8 * fs + 4 * q], nd[0][8 * fs + 4 * q + 1]), m[2 * q]);
+                            dn[fs][2 * q + 1] = mask2(pack2<false>(nd[0][8 * fs + 4 * q + 2], nd[0][8 * fs + 4 * q + 3]), m[2 * q + 1]);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        }
+                    }
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 // the mask / convert step does not need the barrier: it runs while the image stores drain and the other waves arrive
                 if (l > 0) {
 #pragma unroll
-                    for (int s = 0; s < SS; ++s) dfrag[s] = PMB(9) ? raw8(nd[s >> 1], 8 * (s & 1)) : PMB(7) ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
+                    for (int s = 0; s < SS; ++s) {
+                        if (kOvl && s < 2) dfrag[s] = __builtin_bit_cast(bf16x8, dn[s]);
+                        else dfrag[s] = PMB(9) ? raw8(nd[s >> 1], 8 * (s & 1)) : PMB(7) ? pack8<false>(nd[s >> 1], 8 * (s & 1)) : pack8_masked(nd[s >> 1], 8 * (s & 1), afrag[l][s]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #if NNS_PMB_TIMING

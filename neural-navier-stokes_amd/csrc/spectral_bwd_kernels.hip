@@ -232,19 +232,25 @@ __global__ __launch_bounds__(kSpecThreads) void spec_bwd_ypass_kernel(const floa
 // x-pass: columns.  A workgroup owns LINES adjacent columns of one grid; the five input fields go through the LDS
 // transpose stage in two rounds (u, v, a then b, d: the stage holds three fields), the three partials come back in one.
 // ------------------------------------------------------------------------------------------------------------------
-template <int N, typename TF>
-__global__ __launch_bounds__(kSpecThreads) void spec_bwd_xpass_kernel(const float* __restrict__ u, const float* __restrict__ v,
+// WAVES (round 4): lines -- and waves -- per workgroup.  With 8 a CU holds ONE workgroup whose eight waves walk load / stage / transform / store in
+// lockstep (the barriers of the staging steps): the vector pipe idles while the tile's 80 row pieces per thread are in flight and the memory system
+// idles under the six transforms -- 1.7 TB/s, 34 % of wave-cycles issuing (profiles/r04_specbwd_summary.txt).  With 4 the LDS of a workgroup halves
+// and a CU holds TWO that run out of step, one transforming while the other moves its tile -- but its tiles are 4 columns wide: 16-byte row pieces,
+// twice the row pieces per byte.  MEASURED (profiles/r04_ab_specbwd_xwaves.txt, same box, three rounds): whole backward 2.10 ms with 8, 2.17 with 4:
+// the access shape costs more than the overlap buys.  NNS_BWD_XWAVES=4 in the environment selects it for re-measurement.
+template <int N, typename TF, int WAVES>
+__global__ __launch_bounds__(WAVES * kWave) void spec_bwd_xpass_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                                        const float* __restrict__ ga, const float* __restrict__ gb, const float* __restrict__ gd,
                                                                        float* __restrict__ gu, float* __restrict__ gv, float* __restrict__ gp,
                                                                        int ny, int tiles_per_grid, long ntiles, AdjK k) {
-    using L = SpecLds<N, TF>;
+    using L = SpecLds<N, TF, WAVES>;
     constexpr int TPF = L::TPF, CW = L::LINES, SF = L::STAGE_F;
-    constexpr int ROWS_PER_IT = kSpecThreads / CW;
+    constexpr int ROWS_PER_IT = WAVES * kWave / CW;
     constexpr int NR = N / ROWS_PER_IT;
     static_assert(NR == 16, "staging geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     C2<TF>* tabF; C2<float>* tabI; unsigned char* lines;
-    spec_setup<N, TF>(smem, tabF, tabI, lines);
+    spec_setup<N, TF, WAVES * kWave>(smem, tabF, tabI, lines);
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int tx = threadIdx.x;
         asm volatile("" : "+v"(tx));
@@ -318,18 +324,28 @@ int launch_bwd(const float* u, const float* v, const float* ga, const float* gb,
     using L = SpecLds<N, TF>;
     const long gmax = spec_grid_cap();
     if (xpass) {
-        auto kern = spec_bwd_xpass_kernel<N, TF>;
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
-            if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec bwd xpass: hipFuncSetAttribute(%d B): %s", L::TOTAL, hipGetErrorString(e));
-            attr = true;
-        }
-        const int ny = nx_or_ny_other;
-        const int tiles_per_grid = (ny + L::LINES - 1) / L::LINES;
-        const long ntiles = (long)batch * tiles_per_grid;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < gmax ? ntiles : gmax)), dim3(kSpecThreads), L::TOTAL, s, u, v, ga, gb, gd, gu, gv, gp, ny, tiles_per_grid, ntiles, k);
-        return check_launch("spec_residual_bwd_xpass");
+#ifndef NNS_BWD_XWAVES
+#define NNS_BWD_XWAVES 8           // waves (= lines at N = 1024) per workgroup of the backward column pass: 8 = one workgroup per CU, 4 = two out of step (measured slower)
+#endif
+        static const int xw = [] { const char* e = getenv("NNS_BWD_XWAVES"); const int v = e ? atoi(e) : NNS_BWD_XWAVES; return v == 4 ? 4 : 8; }();
+        auto go = [&](auto wc) -> int {
+            constexpr int W = decltype(wc)::value;
+            using LW = SpecLds<N, TF, W>;
+            auto kern = spec_bwd_xpass_kernel<N, TF, W>;
+            static bool attr = false;
+            if (!attr) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LW::TOTAL);
+                if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spec bwd xpass: hipFuncSetAttribute(%d B): %s", LW::TOTAL, hipGetErrorString(e));
+                attr = true;
+            }
+            const int ny = nx_or_ny_other;
+            const int tiles_per_grid = (ny + LW::LINES - 1) / LW::LINES;
+            const long ntiles = (long)batch * tiles_per_grid;
+            const long cap = gmax * (8 / W);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(W * kWave), LW::TOTAL, s, u, v, ga, gb, gd, gu, gv, gp, ny, tiles_per_grid, ntiles, k);
+            return check_launch("spec_residual_bwd_xpass");
+        };
+        return xw == 8 ? go(std::integral_constant<int, 8>{}) : go(std::integral_constant<int, 4>{});
     }
     auto kern = spec_bwd_ypass_kernel<N, TF>;
     static bool attr = false;

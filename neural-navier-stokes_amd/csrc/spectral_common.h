@@ -24,11 +24,11 @@ struct SpecK {
     float inv_dt;
 };
 
-template <int N, typename TF>
+template <int N, typename TF, int WAVES = kSpecWaves>
 struct SpecLds {
     static constexpr int TPF = N / 16;
     static constexpr int FPW = kWave / TPF;                       // lines per wave
-    static constexpr int LINES = kSpecWaves * FPW;                // lines per workgroup
+    static constexpr int LINES = WAVES * FPW;                     // lines per workgroup
     static constexpr int SLOTS = N + N / 16;
     static constexpr int STAGE_F = N + 16;                        // floats per staged field (padded)
     static constexpr int XB_BYTES = SLOTS * (int)sizeof(C2<TF>);

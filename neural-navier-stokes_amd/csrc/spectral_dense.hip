@@ -15,6 +15,7 @@
 #include "spectral_common.h"
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -26,13 +27,23 @@ constexpr int kDenseMax = nns::spec::kDenseMaxLen;
 
 struct Circ { const double* d1; const double* d2; };
 
-// device-resident circulant vectors of (n, L): built once, never freed (a handful of sizes per process)
+// device-resident circulant vectors of (device, n, L): built once per device, never freed (a handful of sizes per process).  The FIRST call
+// for a size builds the table on the host (O(n^2)), allocates and copies synchronously -- none of which may happen while the stream is being
+// captured into a HIP graph: a capture that meets a missing table is refused with a clear message (build it first: any eager call of the
+// same size, or nns_spec_dense_warmup).
 int circulant(int n, double L, hipStream_t s, Circ& out) {
     static std::mutex mu;
-    static std::map<std::pair<int, double>, double*> cache;
+    static std::map<std::tuple<int, int, double>, double*> cache;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spectral (dense): hipGetDevice: %s", hipGetErrorString(e));
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find({n, L});
+    auto it = cache.find({dev, n, L});
     if (it == cache.end()) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(NNS_ERR_UNSUPPORTED, "spectral (dense): the circulant table of n=%d, L=%g is not built yet on device %d and cannot be built during a stream capture "
+                        "(allocation + synchronous copy): call nns_spec_dense_warmup(n, L) or run the step once eagerly before capturing", n, L, dev);
         std::vector<double> h(2 * (size_t)n);
         const int K = (n - 1) / 2;
         const double ks = 2.0 * M_PI / L;
@@ -50,14 +61,13 @@ int circulant(int n, double L, hipStream_t s, Circ& out) {
             h[n + m] = -(2.0 * a2 + nyq) / n;
         }
         double* d = nullptr;
-        hipError_t e = hipMalloc(&d, h.size() * sizeof(double));
+        e = hipMalloc(&d, h.size() * sizeof(double));
         if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "spectral (dense): hipMalloc: %s", hipGetErrorString(e));
         // synchronous copy: the host vector dies at the end of this scope, and the table must be complete before any stream uses it
         e = hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(d); return fail(NNS_ERR_LAUNCH, "spectral (dense): hipMemcpy: %s", hipGetErrorString(e)); }
-        it = cache.emplace(std::make_pair(n, L), d).first;
+        it = cache.emplace(std::make_tuple(dev, n, L), d).first;
     }
-    (void)s;
     out.d1 = it->second;
     out.d2 = it->second + n;
     return NNS_OK;
@@ -209,3 +219,11 @@ int dense_bwd_ypass(const float* u, const float* v, const float* ga, const float
 
 }  // namespace spec
 }  // namespace nns
+
+// Builds (or finds) the circulant table of one axis length on the CURRENT device ahead of time: the only part of the dense path that allocates
+// and synchronises.  Call it once per (n, L) before capturing a stream that evaluates the residual on such an axis.
+NNS_API int nns_spec_dense_warmup(int n, double L) {
+    if (n < 3 || n > nns::spec::kDenseMaxLen || L == 0) return nns::fail(NNS_ERR_INVALID_ARG, "spec_dense_warmup: n=%d must be in [3, %d] and L non-zero", n, nns::spec::kDenseMaxLen);
+    Circ c;
+    return circulant(n, L, nullptr, c);
+}

@@ -173,10 +173,17 @@ struct HaloK { const float* top; const float* bot; long fstride; };
 // [src][field][grid][nx_local][2^shift columns] -- a row of a local grid is P pieces of ny / P floats, one per source rank, `sstride`
 // elements apart -- and the row pass reads them there (SEGP = true) instead of from a copy permuted into row slabs; the finished
 // residuals still go to ru, rv, rd (row slabs).  pu, pv, pd: the three fields' blocks of source rank 0.
-struct PartK { const float* pu; const float* pv; const float* pd; int shift; long sstride; };
-// element offset of slot column jm (a multiple of TPF <= the piece length: wave-uniform) in the segmented layout, relative to the row's
-// offset inside one source rank's block
-__device__ __forceinline__ size_t seg_col(const PartK& pk, int jm) { return (size_t)(jm >> pk.shift) * (size_t)pk.sstride + (size_t)(jm & ((1 << pk.shift) - 1)); }
+struct PartK { const float* pu; const float* pv; const float* pd; int shift; unsigned sstride_bytes; };
+// BYTE offset of slot column jm (a multiple of TPF: wave-uniform, a scalar register) in the segmented layout, relative to the row's offset inside
+// one source rank's block.  The three partial fields share it, and a load is  buffer_load_dword v, v_row, s[descriptor], s_col offen : base
+// (descriptor) + lane's row offset (ONE vector register per row) + this scalar.  (First version: `global_load_dword v, v_row, s[pu + col]` -- the
+// compiler hoisted the 16 slots x 3 fields of 64-bit scalar bases out of the row loop, 96 scalar registers that spilled into vector lanes: 64
+// bytes of scratch per lane and a row pass of 0.84 instead of 0.72 ms at 1024^2 x 64.)
+__device__ __forceinline__ int seg_col(const PartK& pk, int jm) { return (int)((unsigned)(jm >> pk.shift) * pk.sstride_bytes + (unsigned)(jm & ((1 << pk.shift) - 1)) * 4u); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t seg_rsrc(const float* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xffffffffu, 0x00020000); }
+template <bool NT> __device__ __forceinline__ float ld_seg(__amdgpu_buffer_rsrc_t r, unsigned row_bytes, int col_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)row_bytes, col_bytes, NT ? 2 : 0));      // aux bit 1: nt
+}
 #ifndef NNS_YPASS_NT
 #define NNS_YPASS_NT 1            // non-temporal hints on the fused row pass's write-once outputs and read-once streams (0.84 -> 0.78 ms)
 #endif
@@ -185,11 +192,6 @@ __device__ __forceinline__ size_t seg_col(const PartK& pk, int jm) { return (siz
 #endif
 template <bool NT> __device__ __forceinline__ float ld_stream(const float* q) { if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; }
 template <bool NT> __device__ __forceinline__ void st_stream(float* q, float x) { if constexpr (NT) __builtin_nontemporal_store(x, q); else *q = x; }
-// scalar base + 32-bit lane byte offset (global_load_dword v, v_off, s[base]): the segmented partial reads
-template <bool NT> __device__ __forceinline__ float ld_stream_b(const float* q, unsigned byte_off) {
-    const float* a = reinterpret_cast<const float*>(reinterpret_cast<const char*>(q) + byte_off);
-    if constexpr (NT) return __builtin_nontemporal_load(a); else return *a;
-}
 
 // ------------------------------------------------------------------------------------------
 // y-pass: rows (contiguous lines).  One line per TPF lanes; a workgroup iteration handles
@@ -275,8 +277,8 @@ __global__ __launch_bounds__(kSpecThreads) void spec_ypass_kernel(const float* _
                 const size_t c = base + TPF * (8 * h + i);
                 constexpr bool NT = (FUSE_FD || NNS_YPASS_NT_PLAIN) && NNS_YPASS_NT;
                 if constexpr (SEGP) {
-                    const size_t so = seg_col(pk, TPF * (8 * h + i));
-                    pu[i] = ld_stream_b<NT>(pk.pu + so, pbyte); pv[i] = ld_stream_b<NT>(pk.pv + so, pbyte); pd[i] = ld_stream_b<NT>(pk.pd + so, pbyte);
+                    const int so = seg_col(pk, TPF * (8 * h + i));
+                    pu[i] = ld_seg<NT>(seg_rsrc(pk.pu), pbyte, so); pv[i] = ld_seg<NT>(seg_rsrc(pk.pv), pbyte, so); pd[i] = ld_seg<NT>(seg_rsrc(pk.pd), pbyte, so);
                 } else {
                 pu[i] = ld_stream<NT>(ru + c); pv[i] = ld_stream<NT>(rv + c); pd[i] = ld_stream<NT>(rd + c);
                 }
@@ -496,8 +498,8 @@ __global__ __launch_bounds__(kSpecThreads) void spec_rowmarch_kernel(const float
                 for (int i = 0; i < 8; ++i) {
                     const size_t c2 = base + TPF * (8 * h + i);
                     if constexpr (SEGP) {
-                        const size_t so = seg_col(pk, TPF * (8 * h + i));
-                        pu[i] = ld_stream_b<NNS_YPASS_NT>(pk.pu + so, pbyte); pv[i] = ld_stream_b<NNS_YPASS_NT>(pk.pv + so, pbyte); pd[i] = ld_stream_b<NNS_YPASS_NT>(pk.pd + so, pbyte);
+                        const int so = seg_col(pk, TPF * (8 * h + i));
+                        pu[i] = ld_seg<NNS_YPASS_NT>(seg_rsrc(pk.pu), pbyte, so); pv[i] = ld_seg<NNS_YPASS_NT>(seg_rsrc(pk.pv), pbyte, so); pd[i] = ld_seg<NNS_YPASS_NT>(seg_rsrc(pk.pd), pbyte, so);
                     } else {
                     pu[i] = ld_stream<NNS_YPASS_NT>(ru + c2); pv[i] = ld_stream<NNS_YPASS_NT>(rv + c2); pd[i] = ld_stream<NNS_YPASS_NT>(rd + c2);
                     }
@@ -782,6 +784,19 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
         };
         auto at = [](const float* base, unsigned byte_off) -> const float& { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
         auto at_w = [](float* base, unsigned byte_off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off); };
+#ifndef NNS_SPLIT_BUF
+#define NNS_SPLIT_BUF 0            // 1: whole grids (not SEG): buffer loads / stores -- descriptor of the grid + ONE lane offset per tile + a scalar row offset per access
+#endif
+        // Round 4: with `global_load_dword v, v_off, s[base]` every row piece still costs two vector instructions (add the row
+        // stride, shift to bytes: 128 per tile, direction and memory wave, on the SIMDs the transform waves compute on).  A buffer access takes
+        // base (descriptor, 4 SGPRs) + lane offset (ONE VGPR per tile) + scalar offset (the row: scalar unit) -- no vector instruction per access
+        // (checked in the ISA: 192 buffer_load_dword / 192 buffer_store_dword per tile loop, `s_off offen`, no v_add / v_lshl between them).
+        // MEASURED, same box, three rounds (profiles/r04_ab_xpass_buffer_addressing.log): column pass 0.493 ms against 0.490 with the global_
+        // form, step 5.17e10 against 5.22e10 -- no gain: the memory waves' vector instructions were not what the roles cost each other.  Kept
+        // behind the macro, off.
+        constexpr bool BUF = NNS_SPLIT_BUF && !SEG;
+        auto rsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((unsigned)N * (unsigned)ny * 4u), 0x00020000); };
+        auto row_soff = [&](int i) -> int { return (4 * MROWS * (i >> 2) + (i & 3)) * ny * 4; };      // wave-uniform: scalar registers
         auto load_tile = [&](long tt) {
             int j0; size_t g;
             tile_coords(tt, j0, g);
@@ -789,10 +804,22 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
             unsigned crv = (unsigned)cr;
             asm volatile("" : "+v"(col), "+v"(crv));
             const float* ug = u + g; const float* vg = v + g; const float* pg = p + g;
+            if constexpr (BUF) {
+                const auto r0 = rsrc(ug), r1 = rsrc(vg), r2 = rsrc(pg);
+                const int voff = (int)((col + 4u * crv * (unsigned)ny) * 4u);
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int so = row_soff(i);
+                    R[0][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, voff, so, 0));
+                    R[1][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, voff, so, 0));
+                    R[2][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, voff, so, 0));
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const unsigned c = off32(i, col, crv);
                 R[0][i] = at(ug, c); R[1][i] = at(vg, c); R[2][i] = at(pg, c);
+            }
             }
         };
         auto store_tile = [&](long tt) {
@@ -803,10 +830,22 @@ __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const f
                 unsigned crv = (unsigned)cr;
                 asm volatile("" : "+v"(col), "+v"(crv));
                 float* ug = ru + g; float* vg = rv + g; float* pg = rd + g;
+                if constexpr (BUF) {
+                    const auto r0 = rsrc(ug), r1 = rsrc(vg), r2 = rsrc(pg);
+                    const int voff = (int)((col + 4u * crv * (unsigned)ny) * 4u);
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        const int so = row_soff(i);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, R[0][i]), r0, voff, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, R[1][i]), r1, voff, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, R[2][i]), r2, voff, so, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const unsigned c = off32(i, col, crv);
                     at_w(ug, c) = R[0][i]; at_w(vg, c) = R[1][i]; at_w(pg, c) = R[2][i];
+                }
                 }
             }
         };

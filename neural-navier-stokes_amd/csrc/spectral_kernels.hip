@@ -58,6 +58,18 @@ int residual_both(const float* u, const float* v, const float* p, const float* u
     }
     if (!pow2_in_range(ny)) return fail(NNS_ERR_UNSUPPORTED, "residual_both (row slab): ny=%d must be a power of two in [64, 1024]", ny);
     if (with_xpass) {
+        // NNS_BOTH_GROUP=G (a measurement switch, default off): the two launches per GROUP of G grids instead of per batch, so that a group's row pass
+        // follows its column pass while the group's partials and inputs may still be in the 256 MB Infinity Cache.
+        // Measured at 1024^2 x 64 (profiles/r04_grouped_launches.txt): slower at every G -- see DESIGN.md section 7.1.
+        static const int group = [] { const char* e = getenv("NNS_BOTH_GROUP"); return e ? atoi(e) : 0; }();
+        if (group > 0 && group < batch) {
+            for (int g0 = 0; g0 < batch; g0 += group) {
+                const int gb = batch - g0 < group ? batch - g0 : group;
+                const size_t o = (size_t)g0 * nx * ny;
+                if (int rc = residual_both(u + o, v + o, p + o, up + o, vp + o, fu + o, fv + o, fd + o, ru + o, rv + o, rd + o, gb, nx, ny, dt, Lx, Ly, rho, nu, precise, s, true)) return rc;
+            }
+            return NNS_OK;
+        }
         if (int rc = xpass(u, v, p, ru, rv, rd, batch, nx, ny, Lx, rho, nu, precise, s)) return rc;
     }
     const double ks = 2.0 * M_PI / Ly, dx = slab ? Lx : Lx / nx, dy = Ly / ny;          // a row slab passes the grid spacing itself in Lx

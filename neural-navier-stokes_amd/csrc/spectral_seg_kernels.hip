@@ -25,8 +25,10 @@ int check_part(const char* what, const float* pu, const float* pv, const float* 
         return fail(NNS_ERR_INVALID_ARG, "%s: seg_cols=%d must be a power of two in [ny / 16 = %d, ny = %d]", what, seg_cols, ny / 16, ny);
     const long block = (long)batch * nx * seg_cols;                       // one field of one source rank
     if (seg_stride < block) return fail(NNS_ERR_INVALID_ARG, "%s: seg_stride=%ld must be >= batch * nx * seg_cols = %ld", what, seg_stride, block);
-    if (block >= (1L << 30)) return fail(NNS_ERR_UNSUPPORTED, "%s: a source rank's block of %ld elements exceeds the 32-bit byte offsets of the segmented reads", what, block);
-    pk = PartK{pu, pv, pd, __builtin_ctz((unsigned)seg_cols), seg_stride};
+    // 32-bit byte offsets from the field's first block: row offset (< one block) + piece offset (< ny / seg_cols blocks of seg_stride elements)
+    const long span = ((long)(ny / seg_cols) - 1) * seg_stride + block;
+    if (span >= (1L << 30)) return fail(NNS_ERR_UNSUPPORTED, "%s: the partial buffer spans %ld elements per field from its first block: beyond the 32-bit byte offsets of the segmented reads", what, span);
+    pk = PartK{pu, pv, pd, __builtin_ctz((unsigned)seg_cols), (unsigned)(seg_stride * 4)};
     return NNS_OK;
 }
 

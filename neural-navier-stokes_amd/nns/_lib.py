@@ -68,6 +68,7 @@ _SINGLE = {
     'nns_spec_residual_ypass_seg_f32': [_P] * 8 + [_I, _L] + [_P] * 3 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_residual_both_rowpass_halo_seg_f32': [_P] * 10 + [_I, _L] + [_P] * 6 + [_I] * 3 + [_L] + [_D] * 5 + [_I, _P],
     'nns_spec_resolve_precise': [_I, _D, _I, _D, _I, _D],
+    'nns_spec_dense_warmup': [_I, _D],
     'nns_spec_derivs_f32': [_P] * 4 + [_I] * 3 + [_D, _D, _I, _P],
     'nns_spec_rfft2_f32': [_P, _P, _I, _I, _I, _P],
     'nns_spec_irfft2_f32': [_P, _P, _I, _I, _I, _P],
@@ -129,6 +130,56 @@ def lib():
 
 class NnsError(RuntimeError):
     pass
+
+
+class CallRecorder(object):
+    """Records the C-ABI calls made while it is active (function object + the exact ctypes arguments, pointer arrays kept alive) so that
+    a caller whose arguments do not change from step to step -- the slab pipeline of nns/slab.py on fixed buffers -- can REPLAY them without
+    re-validating tensors and rebuilding argument lists in Python (one C call per recorded launch: the host cost of a pipeline stage drops
+    from ~40 us to ~5).  Usage: `with rec.stage(key): ...ops calls...`, later `rec.replay(key)`."""
+
+    def __init__(self):
+        self.stages = {}
+        self._cur = None
+
+    class _Proxy(object):
+        def __init__(self, real, rec):
+            self._real, self._rec = real, rec
+
+        def __getattr__(self, name):
+            f = getattr(self._real, name)
+            rec = self._rec
+
+            def call(*args):
+                if rec._cur is not None and f.restype is C.c_int and name not in ('nns_version', 'nns_spec_resolve_precise'):
+                    rec._cur.append((f, args, name))
+                return f(*args)
+            return call
+
+    def stage(self, key):
+        rec = self
+
+        class _Ctx(object):
+            def __enter__(self_):
+                global _lib
+                lib()
+                rec._cur = rec.stages.setdefault(key, [])
+                del rec._cur[:]
+                self_.saved = _lib
+                _lib = CallRecorder._Proxy(self_.saved, rec)
+
+            def __exit__(self_, *exc):
+                global _lib
+                _lib = self_.saved
+                rec._cur = None
+                return False
+        return _Ctx()
+
+    def replay(self, key):
+        for f, args, name in self.stages[key]:
+            rc = f(*args)
+            if rc != 0:
+                check(rc, name)
 
 
 def check(rc, what):

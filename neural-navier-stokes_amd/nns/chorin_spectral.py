@@ -94,15 +94,15 @@ class NavierStokesSystem():
         return D_sqr
 
     def _get_D_matrix_degrees_minus_2(self, N):
-        x = self._get_gauss_lobatto_points(N)
-        D = np.zeros((N, N))
-        for i in range(1, N - 1):
-            for j in range(1, N - 1):
-                if i != j:
-                    D[i, j] = ((-1) ** (j + 1) * (1. - x[j] ** 2) / ((1. - x[i] ** 2) * (x[i] - x[j])))
-                else:
-                    D[i, i] = 3 * x[i] / (2. * (1. - x[i] ** 2))
-        return D[1:-1, 1:-1]
+        """The reference's interior pressure-derivative matrix (src/chorin_spectral/simulate.py:506-531): for interior nodes i != j
+        D_ij = (-1)^(j+1) (1 - x_j^2) / ((1 - x_i^2)(x_i - x_j)), D_ii = 3 x_i / (2 (1 - x_i^2)); as array expressions."""
+        x = self._get_gauss_lobatto_points(N)[1:-1]
+        w = 1. - x ** 2
+        sign = np.where(np.arange(1, N - 1) % 2 == 0, -1.0, 1.0)               # (-1)^(j+1) at the global node index j
+        with np.errstate(divide='ignore', invalid='ignore'):
+            D = (sign * w)[None, :] / (w[:, None] * (x[:, None] - x[None, :]))
+        np.fill_diagonal(D, 3 * x / (2. * w))
+        return D
 
     def _get_D_matrix_interior_lagrange(self, N):
         """matrices='corrected' only: the exact derivative matrix of the interpolant on the N-2 interior nodes (barycentric

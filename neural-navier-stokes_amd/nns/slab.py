@@ -35,6 +35,7 @@ from ._comm import Transport
 
 class HipCompute(object):
     """The product's compute back-end: hand-written HIP kernels through the C ABI (nns.ops)."""
+    recordable = True            # every method is a sequence of C-ABI calls on its arguments: SlabResidual may record and replay them
 
     def gather_lines(self, fields, msg, nouter, outer_stride, line_off, length, elem_stride=1):
         from . import ops
@@ -124,6 +125,7 @@ class SlabResidual(object):
                 precise = 0 if amp <= 8.0 else 2
         self.precise = precise
         self._bufs = {}
+        self._plans = {}
 
     def _buf(self, name, shape, like):
         """Message buffers are allocated once per shape and reused (a collective in flight owns its buffers until wait())."""
@@ -171,7 +173,7 @@ class SlabResidual(object):
             c = 1
         return max(1, min(int(c), B))
 
-    def _pipeline(self, u, v, p, finish, chunks=None, halo=False):
+    def _pipeline(self, u, v, p, finish, chunks=None, halo=False, rec=None):
         """The spectral path's three stages, software-pipelined over chunks of the batch axis (independent grids):
 
             stage 0 (chunk c):  pack row slabs -> send buffer [dest][u, v, p][Bc][nloc][ny/P] (chunk 0, halo=True: the SAME launch also packs the two
@@ -184,7 +186,8 @@ class SlabResidual(object):
         back to back on the communication stream -- #1(0), #1(1), #2(0), #1(2), #2(1), ... -- while the compute stream packs,
         transforms and finishes other chunks.  Per chunk: 1 copy kernel + 2 collectives + 2 compute kernels (round 3: 2 copy kernels,
         and 2 more launches per step for the halo messages).  Every kernel treats grids independently, so the results do not depend on
-        the chunking (checked bitwise in the tests).  Returns the halo (handle, top, bot) or None."""
+        the chunking (checked bitwise in the tests).  rec: a _lib.CallRecorder -- the C calls of stage k of chunk c are recorded under (c, k) and the
+        buffers of the run are returned for `_both_replay`."""
         B, nloc, ny = u.shape
         P, nyl, c_ = self.P, self.nyloc, self.compute
         C = self._nchunks(B, chunks)
@@ -192,30 +195,41 @@ class SlabResidual(object):
         st = [None] * C
         fields = [u, v, p]
         hal = [None]
+        import contextlib
+        stage = (lambda c, k: rec.stage((c, k))) if rec is not None else (lambda c, k: contextlib.nullcontext())
+        bufs = dict(send=[None] * C, recv=[None] * C, back=[None] * C, got=[None] * C, halo=None)
 
         def s0(c):
             g0, g1 = bounds[c]
             shape = (P, 3, g1 - g0, nloc, nyl)
             send, recv = self._buf(('a2a_s1', c), shape, u), self._buf(('a2a_r1', c), shape, u)
+            bufs['send'][c], bufs['recv'][c] = send, recv
             if c == 0 and halo:
-                first, last, top, bot = self._halo_bufs(u, 3, 0)
-                c_.pack_halo(fields, send, first, last, g0, P)
+                first, last, top, bot = bufs['halo'] = self._halo_bufs(u, 3, 0)
+                with stage(c, 0):
+                    c_.pack_halo(fields, send, first, last, g0, P)
                 hal[0] = (self.tr.ring_exchange(first, last, bot, top, wrap=True), top, bot)
             else:
-                c_.pack_halo(fields, send, None, None, g0, P)
+                with stage(c, 0):
+                    c_.pack_halo(fields, send, None, None, g0, P)
             st[c] = dict(sl=slice(g0, g1), shape=shape, recv=recv, h1=self.tr.all_to_all(recv, send))
 
         def s1(c):
             d = st[c]
             d['h1'].wait()
             back, got = self._buf(('a2a_s2', c), d['shape'], u), self._buf(('a2a_r2', c), d['shape'], u)
-            c_.spec_xpass_seg(d['recv'], back, d['shape'][2], self.nx, nyl, nloc, self.Lx, self.rho, self.nu, self.precise)
+            bufs['back'][c], bufs['got'][c] = back, got
+            with stage(c, 1):
+                c_.spec_xpass_seg(d['recv'], back, d['shape'][2], self.nx, nyl, nloc, self.Lx, self.rho, self.nu, self.precise)
             d['got'], d['h2'] = got, self.tr.all_to_all(got, back)
 
         def s2(c):
             d = st[c]
             d['h2'].wait()
-            finish(c, d['sl'], d['got'], hal[0])
+            if rec is not None and hal[0] is not None and c == 0:
+                hal[0][0].wait()                                   # outside the recorded stage: `_both_replay` waits for the halo itself
+            with stage(c, 2):
+                finish(c, d['sl'], d['got'], hal[0])
 
         for tick in range(C + 2):
             if tick < C:
@@ -224,7 +238,7 @@ class SlabResidual(object):
                 s1(tick - 1)
             if 0 <= tick - 2 < C:
                 s2(tick - 2)
-        return hal[0]
+        return bufs if rec is not None else hal[0]
 
     def spectral(self, u, v, p, u_prev, v_prev, chunks=None):
         c_ = self.compute
@@ -235,14 +249,27 @@ class SlabResidual(object):
         self._pipeline(u, v, p, fin, chunks)
         return out
 
-    def both(self, u, v, p, u_prev, v_prev, stencil=5, chunks=None):
+    def both(self, u, v, p, u_prev, v_prev, stencil=5, chunks=None, out_fd=None, out_spec=None):
         """FD + spectral residual of the same inputs.  5-point stencil, float32: the fused form -- the halo messages are packed by the first
         chunk's pack launch and travel under the two transposes and the column pass, then ONE row pass per chunk does the stencil and finishes
-        the spectral residual, reading the returned partials where the all-to-all put them; the chunks are pipelined (`_pipeline`)."""
+        the spectral residual, reading the returned partials where the all-to-all put them; the chunks are pipelined (`_pipeline`).
+        out_fd / out_spec: caller-owned output triples.  With BOTH given (a training or time-stepping loop that reuses its buffers) the C calls
+        of the first evaluation are recorded and later evaluations on the same tensors replay them (`_both_replay`): the host then spends its
+        time on the collectives' Python entry points only -- 0.36 -> 0.2 ms per step at two chunks (profiles/r04_slab_*.json)."""
         if stencil != 5 or u.dtype not in getattr(self.compute, 'fused_dtypes', (torch.float32,)):
             return self.fd(u, v, p, u_prev, v_prev, stencil), self.spectral(u, v, p, u_prev, v_prev, chunks)
-        out_fd = tuple(torch.empty_like(u) for _ in range(3))
-        out_sp = tuple(torch.empty_like(u) for _ in range(3))
+        fixed = out_fd is not None and out_spec is not None and getattr(self.compute, 'recordable', False)
+        out_fd = out_fd if out_fd is not None else tuple(torch.empty_like(u) for _ in range(3))
+        out_sp = out_spec if out_spec is not None else tuple(torch.empty_like(u) for _ in range(3))
+        C = self._nchunks(u.shape[0], chunks)
+        if fixed:
+            key = (C, tuple(u.shape), torch.cuda.current_stream().cuda_stream) + tuple(t.data_ptr() for t in (u, v, p, u_prev, v_prev) + tuple(out_fd) + tuple(out_sp))
+            plan = self._plans.get(key)
+            if plan is not None:
+                self._both_replay(plan, C)
+                return out_fd, out_sp
+            from ._lib import CallRecorder
+            rec = CallRecorder()
         waited = []
 
         def fin(c, sl, got, hal):
@@ -252,8 +279,40 @@ class SlabResidual(object):
                 waited.append(True)
             self.compute.both_rowpass_halo_seg(u[sl], v[sl], p[sl], u_prev[sl], v_prev[sl], top, bot, got, self.dt, self.dx, self.Ly, self.rho, self.nu,
                                                self.precise, tuple(t[sl] for t in out_fd), tuple(t[sl] for t in out_sp), halo_grid0=sl.start)
-        self._pipeline(u, v, p, fin, chunks, halo=True)
+        if not fixed:
+            self._pipeline(u, v, p, fin, chunks, halo=True)
+            return out_fd, out_sp
+        bufs = self._pipeline(u, v, p, fin, chunks, halo=True, rec=rec)
+        if len(self._plans) >= 4:
+            self._plans.clear()
+        # the plan keeps every tensor its recorded pointers refer to alive
+        self._plans[key] = dict(rec=rec, bufs=bufs, keep=(u, v, p, u_prev, v_prev, out_fd, out_sp))
         return out_fd, out_sp
+
+    def _both_replay(self, plan, C):
+        """The tick structure of `_pipeline` with the recorded C calls in place of the Python compute back-end (same launches, same order,
+        same buffers: the results are those of the recorded evaluation's code path bit for bit)."""
+        rec, bufs, tr = plan['rec'], plan['bufs'], self.tr
+        first, last, top, bot = bufs['halo']
+        h1, h2, hal = [None] * C, [None] * C, None
+        for tick in range(C + 2):
+            if tick < C:
+                c = tick
+                rec.replay((c, 0))
+                if c == 0:
+                    hal = tr.ring_exchange(first, last, bot, top, wrap=True)
+                h1[c] = tr.all_to_all(bufs['recv'][c], bufs['send'][c])
+            if 0 <= tick - 1 < C:
+                c = tick - 1
+                h1[c].wait()
+                rec.replay((c, 1))
+                h2[c] = tr.all_to_all(bufs['got'][c], bufs['back'][c])
+            if 0 <= tick - 2 < C:
+                c = tick - 2
+                h2[c].wait()
+                if c == 0:
+                    hal.wait()
+                rec.replay((c, 2))
 
 
 class HipSorCompute(object):

@@ -1,11 +1,11 @@
-"""Mirror of the reference's ``src/utils.py`` (data-preparation helpers) on the HIP library.
+"""Mirror of the data-preparation helper of the reference's ``src/utils.py`` that is on the scope table (SURVEY.md section 8 row f4:
+``spatial_coarsen``) on the HIP library.  The file's training-loop leftovers (AverageMeter, save_checkpoint, mean_squared_error) are dead code
+in the reference (out of scope) and are not carried here; the drivers' own running-average helper lives in
+nns/neural_spectral/spectral_ode.py.
 
 spatial_coarsen runs on the GPU (``nns_coarsen_*``: one launch for u, v, p; numpy.mean's pairwise add order is
 reproduced in the kernel, so float64 results are bit-identical to the reference's).  No CPU fallback.
 """
-import os
-import shutil
-
 import numpy as np
 import torch
 
@@ -42,34 +42,3 @@ def spatial_coarsen(X, Y, u_seq, v_seq, p_seq, agg_x=4, agg_y=4):
     if as_numpy:
         cu, cv, cp = (a.cpu().numpy() for a in (cu, cv, cp))
     return new_X, new_Y, cu, cv, cp
-
-
-class AverageMeter(object):
-    """Running average of a scalar (src/utils.py:63-78)."""
-
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
-
-    def update(self, val, n=1):
-        self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
-
-
-def save_checkpoint(state, is_best, folder='./', filename='checkpoint.pth.tar'):
-    """torch.save(state) to folder/filename; the best one is also kept as model_best.pth.tar (src/utils.py:80-86)."""
-    os.makedirs(folder, exist_ok=True)
-    path = os.path.join(folder, filename)
-    torch.save(state, path)
-    if is_best:
-        shutil.copyfile(path, os.path.join(folder, 'model_best.pth.tar'))
-
-
-def mean_squared_error(pred, true):
-    """Per-sample mean squared error, averaged over the batch (src/utils.py:89-93)."""
-    b = pred.size(0)
-    return (pred.reshape(b, -1) - true.reshape(b, -1)).pow(2).mean(dim=1).mean()

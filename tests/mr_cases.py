@@ -40,6 +40,11 @@ def rank_residual(rank, world):
         for i in range(3):
             assert torch.equal(bf2[i], bf[i]) and torch.equal(bs2[i], bs[i]), ('both', chunks, i)
             assert np.array_equal(sp2[i].cpu().numpy(), res['spec_%d' % i]), ('spectral', chunks, i)
+    ofd, osp = tuple(torch.empty_like(loc[0]) for _ in range(3)), tuple(torch.empty_like(loc[0]) for _ in range(3))
+    for rep in range(3):                                     # recorded, then replayed twice (caller-owned outputs)
+        s.both(*loc, chunks=2, out_fd=ofd, out_spec=osp)
+        for i in range(3):
+            assert torch.equal(ofd[i], bf[i]) and torch.equal(osp[i], bs[i]), ('both, replayed', rep, i)
     return res
 
 
@@ -72,6 +77,17 @@ def rank_loopback(rank, world):
             for a, b in zip(list(bf) + list(bs), list(ref_bfd) + list(ref_bsp)):
                 assert torch.equal(a, b), ('both', chunks, rep)
             checks += 1
+    # caller-owned outputs: the first evaluation records its C calls, the next ones replay them (SlabResidual._both_replay)
+    for chunks in (1, 2):
+        ofd, osp = tuple(torch.empty_like(d[0]) for _ in range(3)), tuple(torch.empty_like(d[0]) for _ in range(3))
+        for rep in range(3):
+            for t in ofd + osp:
+                t.fill_(float('nan'))
+            bf, bs = s.both(*d, chunks=chunks, out_fd=ofd, out_spec=osp)
+            assert bf is ofd and bs is osp and len(s._plans) >= 1
+            for a, b in zip(list(bf) + list(bs), list(ref_bfd) + list(ref_bsp)):
+                assert torch.equal(a, b), ('both, replayed', chunks, rep)
+        checks += 1
     # the SOR error slots travel as an integer view through all-reduce(MAX) (nns/slab.py SlabPressure.solve_slab_)
     tr = Transport(loopback=True)
     slots = torch.tensor([1.0, 0.25, float('nan'), 0.0], device='cuda')

@@ -52,7 +52,7 @@ def test_rccl_world1_loopback_slab_paths_bitwise(tmp_path, gpu_device):
     """The RCCL branch of the transport on the hardware a one-GPU box offers: ONE rank whose messages go through the RCCL process
     group to itself (tests/mr_cases.py rank_loopback)."""
     parts = run_ranks("loopback", str(tmp_path), world=1, backend="nccl", timeout=300)
-    assert int(parts[0]['checks']) == 6
+    assert int(parts[0]['checks']) == 8
 
 
 def _check_slab_residual(parts):
