@@ -44,6 +44,18 @@ struct SpecLds {
     static constexpr int TOTAL = TABF_BYTES + TABI_BYTES + LINES * LINE_BYTES;
 };
 
+// Role-split column passes (forward: spectral_fwd.h, backward: spectral_bwd_kernels.hip): eight transform waves + four memory waves per workgroup
+constexpr int kSplitThreads = kSpecThreads + 256;
+template <int N, typename TF>
+struct SplitLds {
+    using L = SpecLds<N, TF>;
+    static constexpr int SKEW_DW = N == 64 ? 4 : 8;      // dwords of skew per line (mod 8 lines): the 16-lane groups of the memory waves' b128 exchange hit 64 distinct banks
+                                                         // (N = 64: 128 lines per workgroup, half the skew keeps the image inside 160 KB)
+    static constexpr int STAGE_BYTES = 3 * L::STAGE_F * 4 + 8 * SKEW_DW * 4;
+    static constexpr int LINE_BYTES = ((L::XB_BYTES > STAGE_BYTES ? L::XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
+    static constexpr int TOTAL = L::TABF_BYTES + L::TABI_BYTES + L::LINES * LINE_BYTES;
+};
+
 // Signed wavenumber index of the element in register slot m of lane `te` (element te + TPF m).  N/2 = 8 TPF, so
 // slots 0..7 hold the non-negative wavenumbers and 8..15 the negative ones: no compare except for the Nyquist mode
 // (slot 8 of lane 0), which odd derivatives drop, as in the oracle.

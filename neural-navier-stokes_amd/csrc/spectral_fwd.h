@@ -726,16 +726,7 @@ __global__ __launch_bounds__(kSpecThreads) void spec_xpass_kernel(const float* _
 // barriers.  The row-piece traffic (the 0.43 ms skeleton of this pass) then runs entirely under the transforms.  Without the
 // prefetch registers the transform waves fit 3 waves per SIMD (<= 168 VGPRs), which is what gives the four extra waves a home.
 // ------------------------------------------------------------------------------------------
-constexpr int kSplitThreads = kSpecThreads + 256;
-template <int N, typename TF>
-struct SplitLds {
-    using L = SpecLds<N, TF>;
-    static constexpr int SKEW_DW = N == 64 ? 4 : 8;      // dwords of skew per line (mod 8 lines): the 16-lane groups of the memory waves' b128 exchange hit 64 distinct banks
-                                                         // (N = 64: 128 lines per workgroup, half the skew keeps the image inside 160 KB)
-    static constexpr int STAGE_BYTES = 3 * L::STAGE_F * 4 + 8 * SKEW_DW * 4;
-    static constexpr int LINE_BYTES = ((L::XB_BYTES > STAGE_BYTES ? L::XB_BYTES : STAGE_BYTES) + 127) / 128 * 128;
-    static constexpr int TOTAL = L::TABF_BYTES + L::TABI_BYTES + L::LINES * LINE_BYTES;
-};
+// (kSplitThreads, SplitLds: spectral_common.h -- shared with the backward column pass)
 template <int N, typename TF, bool SEG>
 __global__ __launch_bounds__(kSplitThreads) void spec_xpass_split_kernel(const float* __restrict__ u, const float* __restrict__ v,
                                                                           const float* __restrict__ p, float* __restrict__ ru,
