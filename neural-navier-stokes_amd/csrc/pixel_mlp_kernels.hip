@@ -335,12 +335,22 @@ int launch_fwd_uniform(const float* x, const float* weights, const float* biases
 //     bit 2 and the 16-byte pad per 8 rows supply the other two bits;
 //   * every compile-time quantity (k-step, output tile, first / second piece, layer) stays an IMMEDIATE offset on one lane address.
 // tools/lds_banks.py replays the four patterns under the hardware's bank rules (old layout: 4 LDS cycles per transposing read, new: 2).
+//
+// NNS_PM_LAYOUT = 2 (second step of round 4): the two 8-byte pieces a forward fragment takes from a row (slots h and 2 + h) sit NEXT to each
+// other, so that (a) is ONE ds_read_b128 (4 LDS cycles per KB) instead of a ds_read2_b64 (8) and (c) one 16-byte store:
+//     byte(sub, row, slot) = sub * SUB + 32 row + 8 (2 ((slot & 1) ^ row bit 2 ^ row bit 3) + (slot >> 1)),        no pad rows
+// The 16-lane groups of a 16-byte read are non-contiguous ({0-3, 12-15, 20-27}, ...): rows 8 apart must differ in their 16-byte half -- row
+// bit 3 in the XOR -- and 8 consecutive rows of a 16-byte store need row bit 2 in it.  In a transposing read row bit 3 is the compile-time
+// "second read" bit, so its XOR cannot be an immediate: such reads keep TWO lane addresses (base, base ^ 16) -- one register more.
+#ifndef NNS_PM_LAYOUT
+#define NNS_PM_LAYOUT 2
+#endif
 template <int OT>
 struct BwdLds {
     static constexpr int SS = 2 * OT, CH = 32 * OT;
     static constexpr int NSUB = 2 * OT;                            // 16-column sub-images per image
     static constexpr int sub_bytes(int nrows) {
-        const int b = nrows * 32 + (nrows / 8) * 16;
+        const int b = nrows * 32 + (NNS_PM_LAYOUT == 2 ? 0 : (nrows / 8) * 16);
         return b + ((32 - (b / 4) % 64 + 64) % 64) * 4;           // consecutive sub-images 32 banks apart
     }
     static constexpr int W_SUB = sub_bytes(CH), IMG_SUB = sub_bytes(128);
@@ -352,7 +362,10 @@ struct BwdLds {
 #endif
     __host__ __device__ static int total(int nl) { return nl * (W_BYTES + B_BYTES) + NNS_PM_IMGSETS * 2 * IMG_BYTES; }
     // byte offset of the 8-byte piece `slot` of row `row` inside one sub-image
-    __host__ __device__ static constexpr int piece(int row, int slot) { return 32 * row + 16 * (row >> 3) + 8 * (slot ^ ((row >> 2) & 1)); }
+    __host__ __device__ static constexpr int piece(int row, int slot) {
+        if (NNS_PM_LAYOUT == 2) return 32 * row + 8 * (2 * ((slot & 1) ^ ((row >> 2) & 1) ^ ((row >> 3) & 1)) + (slot >> 1));
+        return 32 * row + 16 * (row >> 3) + 8 * (slot ^ ((row >> 2) & 1));
+    }
     // weight element (row = out, col = in) of a layer's image
     __host__ __device__ static constexpr int w_elem(int row, int col) { return (col >> 4) * W_SUB + piece(row, (col & 15) >> 2) + 2 * (col & 3); }
 };
@@ -368,15 +381,22 @@ __device__ __forceinline__ bf16x8 join8(bf16x4 lo, bf16x4 hi) {
 template <int OT>
 __device__ __forceinline__ bf16x8 frag_w(const unsigned char* wimg, int r, int h, int ot, int s) {
     using U = BwdLds<OT>;
+    if constexpr (NNS_PM_LAYOUT == 2) {
+        const unsigned char* a = wimg + (32 * r + 16 * (h ^ ((r >> 2) & 1) ^ ((r >> 3) & 1))) + (s * U::W_SUB + ot * (32 * 32));
+        return *reinterpret_cast<const bf16x8*>(a);                               // pieces h and 2 + h, adjacent: one ds_read_b128
+    } else {
     const unsigned char* a = wimg + (32 * r + 16 * (r >> 3) + 8 * (h ^ ((r >> 2) & 1))) + (s * U::W_SUB + ot * (32 * 32 + 4 * 16));
     return join8(*reinterpret_cast<const bf16x4*>(a), *reinterpret_cast<const bf16x4*>(a + 16));
+    }
 }
 
 // The lane part of a transposing read's address (frag_t, frag_pix): lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the
 // group's 4 x 16 block; the half's second group (lane bit 4) reads the next sub-image; lane half h' takes rows +4.
 template <int SUB>
-__device__ __forceinline__ int tr_lane(int lane) {
+__device__ __forceinline__ int tr_lane(int lane, int second = 0) {
     const int gl = lane & 15, q = gl >> 2, pp = gl & 3, hp = lane >> 5;
+    if constexpr (NNS_PM_LAYOUT == 2)       // rows 4 hp + q (+ 8 for the second read: row bit 3 joins the XOR): piece pp at 2 ((pp & 1) ^ hp ^ second) + (pp >> 1)
+        return ((lane >> 4) & 1) * SUB + (4 * hp + q) * 32 + 8 * (2 * ((pp & 1) ^ hp ^ second) + (pp >> 1));
     return ((lane >> 4) & 1) * SUB + (4 * hp + q) * 32 + 8 * (pp ^ hp);
 }
 // Transposing fragment read: element j of lane (r, h) = M[16 s + 8 (j>>2) + 4 h + (j&3)][col_block + r] of a weight image (rows = out).
@@ -384,9 +404,15 @@ __device__ __forceinline__ int tr_lane(int lane) {
 template <int OT>
 __device__ __forceinline__ bf16x8 frag_t(const unsigned char* img, int lane, int s, int col_block) {
     using U = BwdLds<OT>;
-    const unsigned char* a0 = img + tr_lane<U::W_SUB>(lane) + ((col_block >> 4) * U::W_SUB + s * (16 * 32 + 2 * 16));
     using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    if constexpr (NNS_PM_LAYOUT == 2) {
+        const int off = (col_block >> 4) * U::W_SUB + s * (16 * 32);
+        return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(img + tr_lane<U::W_SUB>(lane, 0) + off)),
+                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(img + tr_lane<U::W_SUB>(lane, 1) + off + 8 * 32)));
+    } else {
+    const unsigned char* a0 = img + tr_lane<U::W_SUB>(lane) + ((col_block >> 4) * U::W_SUB + s * (16 * 32 + 2 * 16));
     return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + (8 * 32 + 16))));
+    }
 }
 
 // 8 pixels of channel ch_block + r from a [pix][ch] image for the contraction over pixels: element j of lane (r, h) = pixel
@@ -394,14 +420,21 @@ __device__ __forceinline__ bf16x8 frag_t(const unsigned char* img, int lane, int
 template <int OT>
 __device__ __forceinline__ bf16x8 frag_pix(const unsigned char* img, int lane, int s, int ch_block) {
     using U = BwdLds<OT>;
-    const unsigned char* a0 = img + tr_lane<U::IMG_SUB>(lane) + (ch_block >> 4) * U::IMG_SUB + s * (16 * 32 + 2 * 16);
     using lds_v4 = __attribute__((address_space(3))) bf16x4;
+    if constexpr (NNS_PM_LAYOUT == 2) {
+        const int off = (ch_block >> 4) * U::IMG_SUB + s * (16 * 32);
+        return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(img + tr_lane<U::IMG_SUB>(lane, 0) + off)),
+                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(img + tr_lane<U::IMG_SUB>(lane, 1) + off + 8 * 32)));
+    } else {
+    const unsigned char* a0 = img + tr_lane<U::IMG_SUB>(lane) + (ch_block >> 4) * U::IMG_SUB + s * (16 * 32 + 2 * 16);
     return join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + (8 * 32 + 16))));
+    }
 }
 // The lane part of the chain waves' image row stores: row 32 wave + r, piece h (+ 2 for the fragment's second half), sub-image = k-step
 template <int OT>
 __device__ __forceinline__ int img_row_lane(int wave, int r, int h) {
     const int row = 32 * wave + r;
+    if constexpr (NNS_PM_LAYOUT == 2) return 32 * row + 16 * (h ^ ((row >> 2) & 1) ^ ((row >> 3) & 1));     // the fragment's two pieces: 16 contiguous bytes
     return 32 * row + 16 * (row >> 3) + 8 * (h ^ ((row >> 2) & 1));
 }
 
@@ -539,10 +572,11 @@ __global__ __launch_bounds__(256) void pixel_mlp_bwd_uniform_kernel(const float*
 #pragma unroll
                     for (int s = 0; s < SS; ++s) {
                         // fragment elements 0..3 = channels 16 s + 4 h + (0..3): piece h of sub-image s; elements 4..7 = channels 16 s + 8 + 4 h + (0..3): piece 2 + h
+                        constexpr int P2 = NNS_PM_LAYOUT == 2 ? 8 : 16;          // byte distance of the fragment's second piece
                         *reinterpret_cast<bf16x4*>(rowD + s * U::IMG_SUB) = __builtin_shufflevector(dfrag[s], dfrag[s], 0, 1, 2, 3);
-                        *reinterpret_cast<bf16x4*>(rowD + s * U::IMG_SUB + 16) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
+                        *reinterpret_cast<bf16x4*>(rowD + s * U::IMG_SUB + P2) = __builtin_shufflevector(dfrag[s], dfrag[s], 4, 5, 6, 7);
                         *reinterpret_cast<bf16x4*>(rowA + s * U::IMG_SUB) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 0, 1, 2, 3);
-                        *reinterpret_cast<bf16x4*>(rowA + s * U::IMG_SUB + 16) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
+                        *reinterpret_cast<bf16x4*>(rowA + s * U::IMG_SUB + P2) = __builtin_shufflevector(afrag[l][s], afrag[l][s], 4, 5, 6, 7);
                     }
                 }
                 __syncthreads();
@@ -929,7 +963,7 @@ __global__ __launch_bounds__(512) void pixel_mlp_bwd_split_kernel(const float* _
                             const int k = idx * per + j, s = k >> 2;
                             const bf16x8 src = (k & 2) ? afrag[l][s] : dfrag[s];
                             unsigned char* row = (k & 2) ? rowA : rowD;
-                            *reinterpret_cast<bf16x4*>(row + s * U::IMG_SUB + 16 * (k & 1)) = (k & 1) ? __builtin_shufflevector(src, src, 4, 5, 6, 7) : __builtin_shufflevector(src, src, 0, 1, 2, 3);
+                            *reinterpret_cast<bf16x4*>(row + s * U::IMG_SUB + (NNS_PM_LAYOUT == 2 ? 8 : 16) * (k & 1)) = (k & 1) ? __builtin_shufflevector(src, src, 4, 5, 6, 7) : __builtin_shufflevector(src, src, 0, 1, 2, 3);
                         }
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

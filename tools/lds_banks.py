@@ -93,3 +93,32 @@ print('immediates ok: frag_pix', lane_indep(new_frag_pix, [(s, cb, sec) for s in
       'store', lane_indep(lambda s, k: new_store(0, s, k), [(s, k) for s in range(4) for k in (0, 1)]),
       'frag_w', lane_indep(new_frag_w, [(ot, s, sec) for ot in (0, 1) for s in range(4) for sec in (0, 1)]))
 print('sub-image bytes: image', sub_bytes(128), 'x4 =', 4 * sub_bytes(128), ' W', sub_bytes(64), 'x4 =', 4 * sub_bytes(64), '(old: image', 128 * 136, 'W', 64 * 136, ')')
+
+# ---------------- layout 2 as built (csrc/pixel_mlp_kernels.hip, NNS_PM_LAYOUT = 2): the checks the kernel relies on
+def read_b128(addr_fn):        # ds_read_b128: four non-contiguous 16-lane groups, 64 banks, 16 bytes per lane
+    return conflict_cycles([addr_fn(l) for l in range(64)], 16, B128, 64)
+def write_b128(addr_fn):       # ds_write_b128: eight groups of 8 contiguous lanes, 32 banks
+    return conflict_cycles([addr_fn(l) for l in range(64)], 16, G8, 32)
+def piece2(row, slot): return 32 * row + 8 * (2 * ((slot & 1) ^ ((row >> 2) & 1) ^ ((row >> 3) & 1)) + (slot >> 1))
+def sub2(nrows):
+    b = nrows * 32
+    return b + ((32 - (b // 4) % 64 + 64) % 64) * 4
+def l2_frag_w(ot, s): return lambda lane: s * sub2(64) + piece2(32 * ot + (lane & 31), lane >> 5)            # 16 bytes: pieces h, 2 + h
+def l2_tr(nrows, s, cb, sec):
+    def f(lane):
+        gl = lane & 15; q = gl >> 2; pp = gl & 3; b4 = (lane >> 4) & 1; hp = lane >> 5
+        return (cb // 16 + b4) * sub2(nrows) + piece2(16 * s + 8 * sec + 4 * hp + q, pp)
+    return f
+def l2_store(wave, s): return lambda lane: s * sub2(128) + piece2(32 * wave + (lane & 31), lane >> 5)
+assert all(piece2(r, 2 + h) == piece2(r, h) + 8 for r in range(128) for h in (0, 1)), 'the two pieces of a fragment are adjacent'
+print('LAYOUT 2  frag_w b128 cycles (4 = free):', sorted({read_b128(l2_frag_w(ot, s)) for ot in (0, 1) for s in range(4)}),
+      ' tr reads W / images (2 = free):', sorted({tr_read(l2_tr(64, s, cb, sec)) for s in range(4) for cb in (0, 32) for sec in (0, 1)}),
+      sorted({tr_read(l2_tr(128, s, cb, sec)) for s in range(8) for cb in (0, 32) for sec in (0, 1)}),
+      ' 16-byte stores (8 = free):', sorted({write_b128(l2_store(w, s)) for w in range(4) for s in range(4)}))
+# two lane addresses (base, base ^ 16) serve the first / second transposing read; everything else is an immediate
+for nrows in (64, 128):
+    b0 = l2_tr(nrows, 0, 0, 0); b1 = l2_tr(nrows, 0, 0, 1)
+    assert all((b1(l) - 256) == (b0(l) ^ 16) for l in range(64))
+    assert lane_indep(lambda s, cb: l2_tr(nrows, s, cb, 0), [(s, cb) for s in range(nrows // 16) for cb in (0, 32)])
+    assert lane_indep(lambda s, cb: l2_tr(nrows, s, cb, 1), [(s, cb) for s in range(nrows // 16) for cb in (0, 32)])
+print('LAYOUT 2  address forms ok (second transposing read = (first lane address ^ 16) + 256)')
