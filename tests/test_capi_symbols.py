@@ -82,3 +82,27 @@ def test_mirrors_have_no_cpu_fallback():
     # an arbitrary user callable still goes through the reference's generic stepper (API parity, not a kernel fallback)
     out = odesolver(lambda t_, y: -y, torch.ones(1, 2), {'Nt': 4, 'method': 'RK4'})
     assert out.shape == (4, 1, 2) and abs(out[-1, 0, 0].item() - 0.3679) < 1e-3
+
+
+def test_call_recorder_records_and_replays_c_calls():
+    """nns._lib.CallRecorder (the slab step's replay of recorded C-ABI calls on fixed buffers): calls made inside a stage are recorded with their
+    exact arguments and repeated by replay(); a failing status on replay raises like the direct call.  CPU only: the recorded call is one that
+    fails its argument check before any HIP call."""
+    import ctypes as C
+    from nns import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    rec = _lib.CallRecorder()
+    ptrs = (C.c_void_p * 3)(None, None, None)
+    with rec.stage(('chunk', 0)):
+        rc = _lib.lib().nns_slab_pack_halo_f32(ptrs, 3, None, None, None, 4, 3, 2, 8, 64, 4, None)        # g0 + Bc > B, NULL buffers: refused
+        assert rc == -1
+        assert _lib.lib().nns_version() == 1                                                           # queries are not recorded
+    assert not isinstance(_lib.lib(), _lib.CallRecorder._Proxy)                                        # the proxy is gone after the stage
+    assert [name for _, _, name in rec.stages[('chunk', 0)]] == ['nns_slab_pack_halo_f32']
+    with pytest.raises(_lib.NnsError, match='nns_slab_pack_halo_f32'):
+        rec.replay(('chunk', 0))
+    with rec.stage(('chunk', 0)):                                                                      # re-recording a stage replaces it
+        pass
+    rec.replay(('chunk', 0))

@@ -698,3 +698,35 @@ def test_slab_pack_halo_one_launch(B, nloc, ny, P, dtype, g0, Bc, gpu_device):
         w2 = torch.empty_like(send)
         ops.slab_transpose_pack([t[g0:g0 + Bc].contiguous() for t in odd], w2, 4)
         assert torch.equal(send, w2) and torch.equal(first, torch.stack([t[:, 0] for t in odd])) and torch.equal(last, torch.stack([t[:, -1] for t in odd]))
+
+
+def test_dense_path_table_is_built_outside_a_stream_capture(gpu_device):
+    """the circulant table of an axis length the FFT engine does not serve is built (host loop, allocation, synchronous copy) at the
+    first call that needs it -- impossible inside a HIP graph capture.  A capture that meets a missing table is refused with
+    NNS_ERR_UNSUPPORTED (and stays intact); after nns_spec_dense_warmup the same step captures, and the replayed graph gives the eager result."""
+    from nns import ops, _lib
+    n, L2 = 57, 3.21                                         # a size / box length no other test uses: its table cannot exist yet
+    g = torch.Generator(device='cuda'); g.manual_seed(57)
+    d = [torch.randn(2, n, n, device='cuda', generator=g) for _ in range(5)]
+    out = tuple(torch.empty_like(d[0]) for _ in range(3))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with pytest.raises(_lib.NnsError, match='stream capture'):
+            with torch.cuda.graph(graph, stream=side):
+                ops.spec_residual(*d, DT, L2, L2, RHO, NU, out=out)
+    torch.cuda.synchronize()
+    assert _lib.lib().nns_spec_dense_warmup(n, L2) == 0
+    ref = [t.clone() for t in ops.spec_residual(*d, DT, L2, L2, RHO, NU)]
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ops.spec_residual(*d, DT, L2, L2, RHO, NU, out=out)
+    for t in out:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)

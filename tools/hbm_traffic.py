@@ -11,7 +11,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         for r in csv.DictReader(open(f)):
             kn = r['Kernel_Name']
             s = next((n for n in ('fd_residual', 'spec_xpass', 'spec_ypass', 'spec_rowmarch') if n in kn), None)          # spec_xpass also matches spec_xpass_split_kernel
-            if s == 'spec_ypass' and re.search(r'spec_ypass_kernel<[^>]*true>', kn):
+            if s == 'spec_ypass' and re.search(r'spec_ypass_kernel<\d+, \w+, true', kn):        # <N, TF, FUSE_FD = true, SEGP>
                 s = 'both_rowpass_f64_forward'                  # spec_ypass_kernel<N, TF, FUSE_FD = true>: the fused row pass of the float64-forward mode
             if s == 'spec_rowmarch':
                 s = 'both_rowpass'                              # the marching form of the fused row pass (the headline's)

@@ -10,6 +10,7 @@ from nns.synthetic import residual_inputs
 from nns.neural_spectral.physics_informed import FieldStepper, train_step
 n = 512
 layout = sys.argv[1] if len(sys.argv) > 1 else 'bchw'
+backend = sys.argv[2] if len(sys.argv) > 2 else 'fd9'          # 'fd9' | 'fd5' | 'spectral'
 ri = residual_inputs(4, n)
 state = torch.as_tensor(np.stack([np.tile(a, (4, 1, 1)) for a in ri[3:] + ri[2:3]], axis=1), device='cuda')
 target = torch.as_tensor(np.stack([np.tile(a, (4, 1, 1)) for a in ri[:3]], axis=1), device='cuda')
@@ -17,9 +18,9 @@ if layout == 'cm':
     state, target = state.transpose(0, 1).contiguous(), target.transpose(0, 1).contiguous()
 stepper = FieldStepper(8, 64).cuda()
 opt = torch.optim.Adam(stepper.parameters(), lr=1e-4)
-eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend='fd9')
+eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
 for _ in range(3): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout)
 torch.cuda.synchronize()
-print(json.dumps(dict(layout=layout, step_ms=1e3 * (time.perf_counter() - t0) / 10, loss=[float(x) for x in out])))
+print(json.dumps(dict(layout=layout, backend=backend, step_ms=1e3 * (time.perf_counter() - t0) / 10, loss=[float(x) for x in out])))
