@@ -18,17 +18,17 @@ NX, NY, B = 16, 24, 2
 DT, RHO, NU, LX, LY = 1e-2, 1.3, 0.05, 2 * np.pi, 3.0
 
 
-def fields():
+def fields(nx=NX, ny=NY):
     rng = np.random.default_rng(42)
-    return [rng.standard_normal((B, NX, NY)) for _ in range(5)]
+    return [rng.standard_normal((B, nx, ny)) for _ in range(5)]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, NX=NX, NY=NY):
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from nns.slab import SlabResidual
-        f = fields()
+        f = fields(NX, NY)
         nloc = NX // world
         loc = [torch.from_numpy(np.ascontiguousarray(a[:, rank * nloc:(rank + 1) * nloc])) for a in f]
         s = SlabResidual(NX, NY, DT, RHO, NU, LX, LY, compute=OracleCompute())
@@ -74,10 +74,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_slab_decomposition_matches_single_process(world, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    f = fields()
+@pytest.mark.parametrize('world,NX,NY', [(2, NX, NY), (4, NX, NY), (8, 32, 40)])
+def test_slab_decomposition_matches_single_process(world, NX, NY, tmp_path):
+    """(world = 8: the node's rank count -- 4 rows and 5 columns per rank; every rank has two distinct ring neighbours and seven all-to-all peers.)"""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), NX, NY), nprocs=world, join=True)
+    f = fields(NX, NY)
     hx, hy = LX / NX, LY / NY
     ref = {'fd5': OP.fd_residual(*f, DT, hx, hy, RHO, NU, 5), 'fd9': OP.fd_residual(*f, DT, hx, hy, RHO, NU, 9),
            'spec': OP.spectral_residual(*f, DT, LX, LY, RHO, NU)}
