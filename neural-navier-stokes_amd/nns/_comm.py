@@ -35,6 +35,15 @@ class _Works(object):
             w.wait()
 
 
+def _adjacent(a, b):
+    """A flat view over a and b when b starts where a ends in the same storage (both contiguous), else None."""
+    if a is None or b is None or a.dtype != b.dtype or a.device != b.device or not (a.is_contiguous() and b.is_contiguous()):
+        return None
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr() or b.storage_offset() != a.storage_offset() + a.numel():
+        return None
+    return torch.as_strided(a, (a.numel() + b.numel(),), (1,), a.storage_offset())
+
+
 class Transport(object):
     def __init__(self, group=None, loopback=None):
         self.group = group
@@ -85,6 +94,13 @@ class Transport(object):
             return _Done()
         up, down = (r - 1) % P, (r + 1) % P
         has_up, has_down = wrap or r > 0, wrap or r < P - 1
+        if wrap and up == down and not self.loopback:
+            # two ranks on a periodic ring: both neighbours are the SAME peer.  Two messages each way would be told apart only by their posting order
+            # (fine on gloo, documented for grouped NCCL point-to-point, never run between two GPUs here): when the buffers allow it -- `last` directly
+            # behind `first` in memory, `from_up` behind `from_down` (SlabResidual allocates them so) -- ONE message each way carries both rows
+            pair_s, pair_r = _adjacent(first, last), _adjacent(from_down, from_up)
+            if pair_s is not None and pair_r is not None:
+                return self.sendrecv([(pair_s, up)], [(pair_r, up)])           # the peer's (first, last) = my (row below, row above)
         sends, recvs = [], []
         if has_up:
             sends.append((first, up))

@@ -137,8 +137,11 @@ class SlabResidual(object):
 
     # ------------------------------------------------------------------ FD: halo rows
     def _halo_bufs(self, f0, F, tag):
+        """(first, last, top, bot), each [F, B, ny]: `last` lies directly behind `first` and `top` behind `bot` in memory, so that on a two-rank ring
+        (both neighbours the same peer) ONE message each way carries both rows (Transport.ring_exchange)."""
         B, nloc, ny = f0.shape
-        return tuple(self._buf((n, tag), (F, B, ny), f0) for n in ('first', 'last', 'top', 'bot'))
+        send, recv = self._buf(('halo_send', tag), (2, F, B, ny), f0), self._buf(('halo_recv', tag), (2, F, B, ny), f0)
+        return send[0], send[1], recv[1], recv[0]
 
     def start_halo(self, fields, tag=0):
         """fields: list of F [B, nloc, ny] row slabs.  Packs their first / last rows (ONE launch each) and starts the ring

@@ -38,6 +38,19 @@ def _worker(rank, world, port, out, NX=NX, NY=NY):
         for k in range(3):
             np.testing.assert_array_equal(top[k].numpy(), f[k][:, (rank * nloc - 1) % NX])
             np.testing.assert_array_equal(bot[k].numpy(), f[k][:, ((rank + 1) * nloc) % NX])
+        if world == 2:
+            # two ranks: both ring neighbours are the same peer.  SlabResidual's halo buffers are adjacent pairs, so ONE message each way carries
+            # both rows; separate buffers go as two ordered messages -- same rows either way
+            posted = []
+            orig = s.tr.sendrecv
+            s.tr.sendrecv = lambda sends, recvs: (posted.append((len(sends), len(recvs))), orig(sends, recvs))[1]
+            s.start_halo(loc[:3])[0].wait()
+            sep = [torch.empty(3, B, NY, dtype=torch.float64) for _ in range(4)]
+            sep[0].copy_(torch.stack([t[:, 0] for t in loc[:3]])), sep[1].copy_(torch.stack([t[:, -1] for t in loc[:3]]))
+            s.tr.ring_exchange(sep[0], sep[1], sep[2], sep[3], wrap=True).wait()
+            s.tr.sendrecv = orig
+            assert posted == [(1, 1), (2, 2)], posted
+            assert torch.equal(sep[2], bot) and torch.equal(sep[3], top)
         # the all-to-all delivers, from every source rank, its rows of this rank's column block; the return trip inverts it
         nyl = NY // world
         send, recv = torch.empty(world, 3, B, nloc, nyl, dtype=torch.float64), torch.empty(world, 3, B, nloc, nyl, dtype=torch.float64)
