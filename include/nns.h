@@ -476,6 +476,30 @@ int nns_slab_pack_halo_f32(const float* const* fields_host, int nfields, float* 
 int nns_slab_pack_halo_f64(const double* const* fields_host, int nfields, double* send, double* first, double* last, int batch_total, int grid0, int batch,
                            int nloc, int ny, int nranks, void* stream);
 
+/* ---- loss head of the physics-informed training step (the hypothesis of
+ * src/neural_spectral/derivations/derivation.tex:25-34, which the reference states and never implements) ----------------------------------
+ *   pred = state + mlp_out (channels u, v, p);  data = mean (pred - target)^2;  phys = mean r_u^2 + mean r_v^2 + w_div mean r_div^2 of the
+ *   residual of pred;  total = data + lam phys.   Three HBM-bound passes replace the tensor ops between the MLP and the residual kernels
+ *   (csrc/pinn_kernels.hip); the sums are deterministic (fixed grid, partials in double added in index order).
+ * workspace: nns_pinn_workspace_bytes() bytes of device memory, 8-byte aligned, ZEROED ONCE by the caller (the kernels leave it reusable),
+ * one per stream in flight. */
+long nns_pinn_workspace_bytes(void);
+/* assemble: out, state, target [batch][3][npix] (target NULL: no data term) -> u, v, p [batch][npix] = the channels of state + out;
+ * u_prev, v_prev [batch][npix] = channels 0, 1 of state (both NULL when the caller already has them contiguous: batch = 1); the data term's
+ * sum of squares stays in the workspace for nns_pinn_loss_f32. */
+int nns_pinn_assemble_f32(const float* out, const float* state, const float* target, float* u, float* v, float* p, float* u_prev, float* v_prev,
+                          void* workspace, int batch, long npix, void* stream);
+/* loss: the residual fields r_u, r_v, r_div (n values each) of the assembled prediction -> out3 (device) = (total, data, phys); n_data = the
+ * number of values under the data mean (3 batch npix; 0: no target).  When w_div != 1, r_div is SCALED IN PLACE by w_div so that the residual
+ * adjoint applied to (r_u, r_v, r_div) as they stand gives (n / 2) d phys / d (u, v, p). */
+int nns_pinn_loss_f32(const float* r_u, const float* r_v, float* r_div, long n, void* workspace, double n_data, double lam, double w_div, float* out3,
+                      void* stream);
+/* combine: grad_out [batch][3][npix] = up_data[0] c_data (pred - target) + up_phys[0] c_phys (g_u, g_v, g_p), pred = (u, v, p) [batch][npix],
+ * (g_u, g_v, g_p) = the residual adjoint's output; up_* are DEVICE scalars (autograd's upstream gradient: no host read-back), c_data = 2 / n_data,
+ * c_phys = 2 lam / n.  target NULL: the physics part alone (u, v, p, up_data unused). */
+int nns_pinn_combine_f32(const float* g_u, const float* g_v, const float* g_p, const float* u, const float* v, const float* p, const float* target,
+                         const float* up_data, const float* up_phys, double c_data, double c_phys, float* grad_out, int batch, long npix, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,10 @@ _SINGLE = {
     'nns_basis_loss_fwd_f32': [_P] * 4 + [_I] * 4 + [_P],
     'nns_basis_loss_bwd_f32': [_P] * 3 + [C.c_float] + [_P] * 2 + [_I] * 4 + [_P],
     'nns_basis_loss_fused_f32': [_P] * 6 + [_I] * 4 + [_P],
+    'nns_pinn_workspace_bytes': [],
+    'nns_pinn_assemble_f32': [_P] * 9 + [_I, _L, _P],
+    'nns_pinn_loss_f32': [_P] * 3 + [_L, _P, _D, _D, _D, _P, _P],
+    'nns_pinn_combine_f32': [_P] * 9 + [_D, _D, _P, _I, _L, _P],
     'nns_fd_predictor_adi_workspace': [_I, _I, _I, _I],
     'nns_fd_sor_workspace': [_I, _I, _I, _I],
     'nns_fd_sor_redblack_workspace': [_I, _I, _I, _I, _I],
@@ -96,7 +100,7 @@ _SINGLE = {
     'nns_version': [],
     'nns_last_error': [],
 }
-_RESTYPES = {'nns_ode_mlp_bwd_workspace': _SZ, 'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_fd_sor_redblack_workspace': _SZ, 'nns_last_error': C.c_char_p}
+_RESTYPES = {'nns_pinn_workspace_bytes': _L, 'nns_ode_mlp_bwd_workspace': _SZ, 'nns_fd_predictor_adi_workspace': _SZ, 'nns_fd_sor_workspace': _SZ, 'nns_fd_sor_redblack_workspace': _SZ, 'nns_last_error': C.c_char_p}
 
 
 def exported_names():

@@ -786,3 +786,79 @@ def spec_irfft2(spec, ny):
     f = torch.empty((B, nx, ny), dtype=torch.float32, device=spec.device)
     check(_lib.lib().nns_spec_irfft2_f32(_p(s), _p(f), B, nx, ny, _stream()), 'nns_spec_irfft2_f32')
     return f
+
+
+# ----------------------------------------------------------------------------- physics-informed loss head
+_PINN_WS = {}
+
+
+def _pinn_ws(device):
+    """The head's workspace (per-block partial sums + the arrival counter), zeroed once per device and stream."""
+    key = (device, _stream())
+    if key not in _PINN_WS:
+        _PINN_WS[key] = torch.zeros(int(_lib.lib().nns_pinn_workspace_bytes()) // 8 + 1, dtype=torch.float64, device=device)
+    return _PINN_WS[key]
+
+
+class PinnHeadFn(torch.autograd.Function):
+    """total, data, phys = head(mlp_out, state, target): pred = state + mlp_out, data = mean (pred - target)^2, phys = mean-square residual of pred,
+    total = data + lam phys (nns/neural_spectral/physics_informed.py) as ONE autograd node: nns_pinn_assemble_f32 -> the residual kernel ->
+    nns_pinn_loss_f32 forward; the residual adjoint -> nns_pinn_combine_f32 backward.  mlp_out, state, target: contiguous float32 [batch, 3, ...]
+    (channel-major fields: batch = 1); `residual` = (kind, consts): ('fd', (dt, dx, dy, rho, nu, stencil)) or ('spectral', (dt, Lx, Ly, rho, nu, precise));
+    dims = the fields' (B, nx, ny)."""
+
+    @staticmethod
+    def forward(ctx, out, state, target, residual, dims, lam, w_div):
+        for t in (out, state) + ((target,) if target is not None else ()):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == out.shape):
+                raise ValueError("PinnHeadFn: mlp_out, state and target must be contiguous float32 device tensors of one shape")
+        B, nx, ny = dims
+        batch, npix = out.shape[0], out[0, 0].numel()
+        if out.shape[1] != 3 or batch * npix != B * nx * ny:
+            raise ValueError("PinnHeadFn: fields [batch, 3, ...] with batch x pixels = %d x %d x %d expected, got %s" % (B, nx, ny, tuple(out.shape)))
+        L, st, ws = _lib.lib(), _stream(), _pinn_ws(out.device)
+        new = lambda: torch.empty((B, nx, ny), dtype=torch.float32, device=out.device)
+        u, v, p = new(), new(), new()
+        if batch == 1:                                   # channel-major: the state's channels ARE contiguous fields
+            u_prev, v_prev, pu, pv = state[0, 0].reshape(B, nx, ny), state[0, 1].reshape(B, nx, ny), None, None
+        else:
+            u_prev, v_prev = new(), new()
+            pu, pv = _p(u_prev), _p(v_prev)
+        check(L.nns_pinn_assemble_f32(_p(out), _p(state), _p(target) if target is not None else None, _p(u), _p(v), _p(p), pu, pv, _p(ws),
+                                      batch, npix, st), 'nns_pinn_assemble_f32')
+        kind, c = residual
+        if kind == 'fd':
+            r = fd_residual(u, v, p, u_prev, v_prev, *c)
+        else:
+            r = spec_residual(u, v, p, u_prev, v_prev, *c)
+        out3 = torch.empty(3, dtype=torch.float32, device=out.device)
+        n = B * nx * ny
+        n_data = 3.0 * n if target is not None else 0.0
+        check(L.nns_pinn_loss_f32(_p(r[0]), _p(r[1]), _p(r[2]), n, _p(ws), n_data, float(lam), float(w_div), _p(out3), st), 'nns_pinn_loss_f32')
+        ctx.save_for_backward(u, v, p, r[0], r[1], r[2], target)
+        ctx.consts = (residual, (B, nx, ny), batch, npix, float(lam), n, n_data, out.shape)
+        ctx.set_materialize_grads(False)
+        return out3.unbind(0)                            # total, data, phys
+
+    @staticmethod
+    def backward(ctx, g_total, g_data, g_phys):
+        u, v, p, ru, rv, rd, target = ctx.saved_tensors
+        residual, (B, nx, ny), batch, npix, lam, n, n_data, shape = ctx.consts
+        kind, c = residual
+        if kind == 'fd':
+            gu, gv, gp, _, _ = fd_residual_bwd(u, v, ru, rv, rd, *c, want_prev=False)
+        else:
+            gu, gv, gp, _, _ = spec_residual_bwd(u, v, ru, rv, rd, *c, want_prev=False)
+        zero = lambda g: torch.zeros((), dtype=torch.float32, device=u.device) if g is None else g.to(torch.float32)
+        if g_data is None and g_phys is None:            # the training step: total.backward()
+            up_d = up_p = zero(g_total).contiguous()
+            c_phys = 2.0 * lam / n
+        else:                                            # someone differentiates the parts: d/d data = g_total + g_data, d/d phys = lam g_total + g_phys
+            up_d = (zero(g_total) + zero(g_data)).contiguous()
+            up_p = (lam * zero(g_total) + zero(g_phys)).contiguous()
+            c_phys = 2.0 / n
+        grad = torch.empty(shape, dtype=torch.float32, device=u.device)
+        check(_lib.lib().nns_pinn_combine_f32(_p(gu), _p(gv), _p(gp), _p(u), _p(v), _p(p), _p(target) if target is not None else None,
+                                              _p(up_d), _p(up_p), 2.0 / n_data if n_data else 0.0, c_phys, _p(grad), batch, npix, _stream()),
+              'nns_pinn_combine_f32')
+        return grad, None, None, None, None, None, None

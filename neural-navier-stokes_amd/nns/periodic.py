@@ -49,6 +49,12 @@ class ResidualEngine(object):
             return ops.SpecResidualFn.apply(u, v, p, u_prev, v_prev, self.dt, self.Lx, self.Ly, self.rho, self.nu, self.precise)
         return ops.FdResidualFn.apply(u, v, p, u_prev, v_prev, self.dt, self.dx, self.dy, self.rho, self.nu, 5 if self.backend == 'fd5' else 9)
 
+    def residual_spec(self):
+        """(kind, constants) of this engine's residual as ops.PinnHeadFn takes it."""
+        if self.backend == 'spectral':
+            return 'spectral', (self.dt, self.Lx, self.Ly, self.rho, self.nu, self.precise)
+        return 'fd', (self.dt, self.dx, self.dy, self.rho, self.nu, 5 if self.backend == 'fd5' else 9)
+
     def physics_loss(self, u, v, p, u_prev, v_prev, w_div=1.0):
         """Mean-square momentum + divergence residual: the physics-informed loss term of SURVEY.md section 8 (f) rank 2
         (hypothesis: src/neural_spectral/derivations/derivation.tex:25-34)."""

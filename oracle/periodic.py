@@ -163,3 +163,24 @@ def spectral_ypart(u, v, p, u_prev, v_prev, pu, pv, pd, dt, Ly, rho, nu):
     r_u = (u - u_prev) / dt + pu + v * uy - nu * uyy
     r_v = (v - v_prev) / dt + pv + v * vy + py / rho - nu * vyy
     return r_u, r_v, pd + vy
+
+
+def pinn_head(out, state, target, backend, consts, lam=1.0, w_div=1.0):
+    """Loss head of the physics-informed step (float64): out, state, target [B, 3, nx, ny] (target None: no data term);
+    pred = state + out (channels u, v, p); data = mean (pred - target)^2; phys = mean r_u^2 + mean r_v^2 + w_div mean r_div^2 of the
+    residual of pred against (state[:, 0], state[:, 1]); total = data + lam phys.  backend 'fd' (consts = dt, dx, dy, rho, nu, stencil)
+    or 'spectral' (consts = dt, Lx, Ly, rho, nu).  Returns (total, data, phys, d total / d out).
+    The reference states this objective and never implements it (src/neural_spectral/derivations/derivation.tex:25-34)."""
+    pred = state + out
+    u, v, p = pred[:, 0], pred[:, 1], pred[:, 2]
+    res, vjp = (fd_residual, fd_residual_vjp) if backend == 'fd' else (spectral_residual, spectral_residual_vjp)
+    r = res(u, v, p, state[:, 0], state[:, 1], *consts)
+    n = u.size
+    phys = (r[0] ** 2).mean() + (r[1] ** 2).mean() + w_div * (r[2] ** 2).mean()
+    g = vjp(u, v, 2 * lam / n * r[0], 2 * lam / n * r[1], 2 * lam * w_div / n * r[2], *consts)
+    grad = np.stack(g[:3], axis=1)
+    data = 0.0
+    if target is not None:
+        data = ((pred - target) ** 2).mean()
+        grad = grad + 2.0 * (pred - target) / pred.size
+    return data + lam * phys, data, phys, grad

@@ -45,7 +45,7 @@ for base, args in _lib._DUAL.items():
     names[base + '_f32'] = args
     names[base + '_f64'] = args
 queries = ('nns_version', 'nns_last_error', 'nns_device_info', 'nns_ode_mlp_bwd_workspace', 'nns_fd_predictor_adi_workspace', 'nns_fd_sor_workspace',
-           'nns_fd_sor_redblack_workspace', 'nns_spec_resolve_precise')
+           'nns_fd_sor_redblack_workspace', 'nns_spec_resolve_precise', 'nns_pinn_workspace_bytes')
 for name, argtypes in sorted(names.items()):
     if name in queries:
         continue
@@ -112,6 +112,11 @@ expect('slab transpose ny % P', L.nns_slab_transpose_pack_f32(ptrs5, 3, P, 1, 4,
 expect('slab pack_halo g0 + Bc > B', L.nns_slab_pack_halo_f32(ptrs5, 3, P, P, P, 4, 3, 2, 8, 64, 4, None), INVALID)
 expect('slab pack_halo one halo buffer', L.nns_slab_pack_halo_f64(ptrs5, 3, P, P, None, 4, 0, 2, 8, 64, 4, None), INVALID)
 expect('slab pack_halo ny / P not a vector multiple', L.nns_slab_pack_halo_f32(ptrs5, 3, P, None, None, 4, 0, 2, 8, 12, 4, None), UNSUPPORTED)
+assert L.nns_pinn_workspace_bytes() >= 4 * 1024 * 8
+expect('pinn assemble one prev field', L.nns_pinn_assemble_f32(P, P, P, P, P, P, P, None, P, 2, 64, None), INVALID)
+expect('pinn assemble misaligned workspace', L.nns_pinn_assemble_f32(P, P, P, P, P, P, None, None, P + 4, 2, 64, None), INVALID)
+expect('pinn loss n = 0', L.nns_pinn_loss_f32(P, P, P, 0, P, 0.0, 1.0, 1.0, P, None), INVALID)
+expect('pinn combine target without fields', L.nns_pinn_combine_f32(P, P, P, None, None, None, P, P, P, 1.0, 1.0, P, 1, 64, None), INVALID)
 expect('coarsen agg', L.nns_coarsen_f32(P, P, P, P, P, P, 2, 8, 8, 3, 3, 2, None), (INVALID, UNSUPPORTED))
 expect('cheb_gemm M=0', L.nns_cheb_gemm_f64(P, 4, 0, P, 4, 0, P, 4, 0, 4, 4, 1.0, 0.0, 1, None), (INVALID, UNSUPPORTED))
 expect('rfft2 nx=48', L.nns_spec_rfft2_f32(P, P, 1, 48, 64, None), (INVALID, UNSUPPORTED))

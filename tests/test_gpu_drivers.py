@@ -89,6 +89,14 @@ def test_physics_informed_training_step(gpu_device):
     for got, q in zip(saved, model.parameters()):
         num = (got - q.grad).norm().item(); den = q.grad.norm().item()
         assert num < 6e-2 * den + 1e-6, (num, den)
+    # the fused loss head (default, round 4) against the same graph from tensor ops around ResidualEngine.differentiable
+    for q in model.parameters():
+        q.grad = None
+    t_un, d_un, p_un = physics_informed_loss(model, eng, state, target, lam=0.1, fused=False)
+    t_un.backward()
+    assert abs(t_un.item() - total.item()) < 1e-5 * abs(total.item())
+    for got, q in zip(saved, model.parameters()):
+        assert (got - q.grad).norm().item() < 2e-3 * got.norm().item() + 1e-7
     # channel-major layout: the same loss and the same gradients (same kernels, other pixel order)
     for q in model.parameters():
         q.grad = None
@@ -146,3 +154,55 @@ def test_physics_informed_spectral_loss_on_reference_driver_grids(gpu_device):
     opt = torch.optim.Adam(model.parameters(), lr=2e-3)
     hist = [train_step(model, eng, opt, state, target, lam=1e-6)[0].item() for _ in range(30)]
     assert np.isfinite(hist).all() and hist[-1] < hist[0], hist[::6]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['fd9_vec', 'fd5_wdiv', 'spectral_odd', 'spectral_pow2_channel_major', 'no_target'])
+def test_physics_informed_loss_head_matches_the_oracle(case, gpu_device):
+    """ops.PinnHeadFn (nns_pinn_assemble_f32 -> residual -> nns_pinn_loss_f32; adjoint -> nns_pinn_combine_f32) against oracle pinn_head in
+    float64: the three losses and d total / d mlp_out, float4 and scalar (odd pixel count) paths, w_div != 1 (r_div scaled in place), no data
+    term, channel-major fields; twice the same bits (the sums are deterministic); and the parts differentiated separately."""
+    import numpy as np
+    import torch
+    from nns import ops
+    from nns.periodic import ResidualEngine
+    from oracle import periodic as OP
+    from conftest import rel_l2
+    B, n, backend, w_div, lam, with_target, cm = dict(
+        fd9_vec=(3, 64, 'fd9', 1.0, 0.1, True, False), fd5_wdiv=(2, 48, 'fd5', 2.5, 0.3, True, False), spectral_odd=(5, 51, 'spectral', 1.5, 1e-3, True, False),
+        spectral_pow2_channel_major=(4, 128, 'spectral', 1.0, 1e-2, True, True), no_target=(3, 37, 'fd9', 2.0, 1.0, False, False))[case]
+    dt, rho, nu, L = 1e-2, 1.3, 0.05, 2.0
+    rng = np.random.default_rng(11)
+    out, state, target = (rng.standard_normal((B, 3, n, n)).astype(np.float32) * s for s in (0.1, 1.0, 1.0))
+    eng = ResidualEngine(n, n, dt, rho, nu, L, L, backend=backend)
+    kind, consts = eng.residual_spec()
+    oc = consts if kind == 'fd' else consts[:5]
+    want = OP.pinn_head(out.astype(np.float64), state.astype(np.float64), target.astype(np.float64) if with_target else None, kind, oc, lam, w_div)
+
+    def dev(a):
+        a = np.ascontiguousarray(a.transpose(1, 0, 2, 3)).reshape(1, 3, -1) if cm else a
+        return torch.as_tensor(a, device='cuda')
+
+    def run():
+        o = dev(out).requires_grad_(True)
+        t3 = ops.PinnHeadFn.apply(o, dev(state), dev(target) if with_target else None, (kind, consts), (B, n, n), lam, w_div)
+        t3[0].backward()
+        g = o.grad.cpu().numpy()
+        g = g.reshape(3, B, n, n).transpose(1, 0, 2, 3) if cm else g
+        return [float(x) for x in t3], g, o
+
+    got, grad, _ = run()
+    for a, b in zip(got, want[:3]):
+        assert abs(a - b) <= 2e-5 * abs(b) + 1e-12, (got, want[:3])
+    assert rel_l2(grad, want[3]) <= 2e-5, rel_l2(grad, want[3])
+    got2, grad2, _ = run()
+    assert got2 == got and np.array_equal(grad, grad2)
+    # d (3 data + 5 phys) / d out through the separate outputs = the oracle's gradient with the two terms reweighted
+    o = dev(out).requires_grad_(True)
+    t3 = ops.PinnHeadFn.apply(o, dev(state), dev(target) if with_target else None, (kind, consts), (B, n, n), lam, w_div)
+    (3.0 * t3[1] + 5.0 * t3[2]).backward()
+    g_phys = OP.pinn_head(out.astype(np.float64), state.astype(np.float64), None, kind, oc, 1.0, w_div)[3]
+    g_data = (want[3] - lam * g_phys) if with_target else 0.0
+    g = o.grad.cpu().numpy()
+    g = g.reshape(3, B, n, n).transpose(1, 0, 2, 3) if cm else g
+    assert rel_l2(g, 3.0 * g_data + 5.0 * g_phys) <= 2e-5

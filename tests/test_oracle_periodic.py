@@ -133,3 +133,20 @@ def test_forward_difference_filters_reproduce_the_spectral_derivatives(n):
     want_xx = np.fft.ifft(np.fft.fft(f, axis=1) * (-(ks * k) ** 2)[None, :, None], axis=1).real
     np.testing.assert_allclose(got_x, fx, atol=1e-10 * np.abs(fx).max())
     np.testing.assert_allclose(got_xx, want_xx, atol=1e-10 * np.abs(want_xx).max())
+
+
+@pytest.mark.parametrize('backend', ['fd', 'spectral'])
+def test_pinn_head_gradient_is_the_derivative_of_its_total(backend):
+    """oracle pinn_head (the loss head of the physics-informed step): its gradient against a central difference of its own total
+    (the total is a quartic polynomial of `out`: the difference quotient is accurate to O(eps^2))."""
+    rng = np.random.default_rng(5)
+    B, n = 2, 12
+    out, state, target = (rng.standard_normal((B, 3, n, n)) * s for s in (0.1, 1.0, 1.0))
+    consts = (1e-2, 0.3, 0.25, 1.3, 0.05, 9) if backend == 'fd' else (1e-2, 2 * np.pi, 3.0, 1.3, 0.05)
+    for tg, w_div in ((target, 2.0), (None, 1.0)):
+        total, data, phys, grad = OP.pinn_head(out, state, tg, backend, consts, lam=0.3, w_div=w_div)
+        assert abs(total - (data + 0.3 * phys)) <= 1e-12 * abs(total) and (tg is not None or data == 0.0)
+        d = rng.standard_normal(out.shape)
+        eps = 1e-5
+        num = (OP.pinn_head(out + eps * d, state, tg, backend, consts, 0.3, w_div)[0] - OP.pinn_head(out - eps * d, state, tg, backend, consts, 0.3, w_div)[0]) / (2 * eps)
+        assert abs(num - (grad * d).sum()) <= 1e-6 * abs(num)

@@ -19,8 +19,9 @@ if layout == 'cm':
 stepper = FieldStepper(8, 64).cuda()
 opt = torch.optim.Adam(stepper.parameters(), lr=1e-4)
 eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
-for _ in range(3): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout)
+fused = os.environ.get('NNS_PINN_FUSED', '1') != '0'
+for _ in range(3): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout, fused=fused)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout)
+for _ in range(10): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout, fused=fused)
 torch.cuda.synchronize()
-print(json.dumps(dict(layout=layout, backend=backend, step_ms=1e3 * (time.perf_counter() - t0) / 10, loss=[float(x) for x in out])))
+print(json.dumps(dict(layout=layout, backend=backend, fused_head=fused, step_ms=1e3 * (time.perf_counter() - t0) / 10, loss=[float(x) for x in out])))
