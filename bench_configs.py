@@ -145,7 +145,8 @@ def cfg2():
     m = PDEFunc(K, n, n).cuda()
     obs = torch.randn(nt, 1, 3, n, n, device='cuda')
     t = torch.arange(nt, device='cuda') + 1
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    import nns.optim as nns_optim
+    opt = nns_optim.Adam(m.parameters(), lr=1e-3)
 
     def it():
         opt.zero_grad()
@@ -187,7 +188,8 @@ def cfg3():
     target = torch.as_tensor(np.stack([np.tile(a, (4, 1, 1)) for a in residual_inputs(4, n)[:3]], axis=1), device='cuda')
     for backend in ('fd9', 'spectral'):
         stepper = FieldStepper(8, 64).cuda()
-        opt = torch.optim.Adam(stepper.parameters(), lr=1e-4)
+        import nns.optim as nns_optim
+        opt = nns_optim.Adam(stepper.parameters(), lr=1e-4)
         e2 = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
         ts = timeit(lambda: train_step(stepper, e2, opt, state, target, lam=0.1), iters=10)
         out['physics_informed_step_d8_w64_bf16_%s' % backend] = dict(ms=1e3 * ts, Mpix_s=16 * n * n / ts / 1e6)
@@ -247,7 +249,8 @@ def secondary(cpu=True):
     m = PDEFunc(K, n, n).cuda()
     obs = torch.randn(nt, 1, 3, n, n, device='cuda')
     t = torch.arange(nt, device='cuda') + 1
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    import nns.optim as nns_optim
+    opt = nns_optim.Adam(m.parameters(), lr=1e-3)
 
     def it2():
         opt.zero_grad()

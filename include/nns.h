@@ -500,6 +500,15 @@ int nns_pinn_loss_f32(const float* r_u, const float* r_v, float* r_div, long n, 
 int nns_pinn_combine_f32(const float* g_u, const float* g_v, const float* g_p, const float* u, const float* v, const float* p, const float* target,
                          const float* up_data, const float* up_phys, double c_data, double c_phys, float* grad_out, int batch, long npix, void* stream);
 
+/* ---- optimiser step (src/neural_spectral/spectral_ode.py:171,189; spectral_ode2.py:159,171; rnn.py:90,102; spectral_rnn.py:131,149:
+ * torch.optim.Adam(model.parameters(), lr=1e-3) ... optimizer.step()) as ONE launch over all parameter tensors -------------------------------
+ * Tables of ntensors device pointers (host arrays) and element counts; float32, contiguous; exp_avg / exp_avg_sq are the optimiser state, updated
+ * in place like the parameters.  Arithmetic in torch's order (no amsgrad): g = grad (+ weight_decay p; maximize: -grad), m += (1 - beta1)(g - m),
+ * v = beta2 v + (1 - beta2) g g, p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps); `step` counts from 1. */
+int nns_adam_step_f32(float* const* params_host, const float* const* grads_host, float* const* exp_avg_host, float* const* exp_avg_sq_host,
+                      const long* sizes_host, int ntensors, double lr, double beta1, double beta2, double eps, double weight_decay, long step,
+                      int maximize, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

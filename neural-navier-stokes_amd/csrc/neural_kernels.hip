@@ -998,6 +998,12 @@ __global__ __launch_bounds__(256) NNS_PK_ATTR void basis_loss_pk_kernel(const fl
 #ifndef NNS_MF_EXP
 #define NNS_MF_EXP 0               // timing experiments (wrong results): 1 no observation loads, 2 no coefficient-gradient part, 3 no LDS accumulation
 #endif
+// gcoeff is accumulated with atomics (always), gbasis too when the time rows are split over workgroups: zeroed in ONE launch
+inline int zero_grads(float* gcoeff, float* gbasis, int nsplit, int T, int K, int C, int P, hipStream_t s) {
+    void* const bufs[2] = {gcoeff, gbasis};
+    const long bytes[2] = {(long)T * K * C * 4, nsplit > 1 ? (long)K * C * P * 4 : 0};
+    return zero_buffers(bufs, bytes, 2, s);
+}
 constexpr int kMfNPT = 4;                                   // pixel tiles (of 16) per wave
 #ifndef NNS_MF_WAVES
 #define NNS_MF_WAVES 3             // waves per SIMD the register allocation is held to (0: the allocator decides -- 2 at K = 10, no spills)
@@ -1296,17 +1302,13 @@ static int ode_mlp_bwd_impl(const char* what, const float* z0, const float* W0, 
         attr = true;
     }
     hipStream_t s = S(stream);
-    // the parameter gradients are accumulated with atomics: zero them first (stream-ordered memset nodes)
-    hipError_t e = hipSuccess;
+    // the parameter gradients are accumulated with atomics: zero them first -- ONE launch for the six buffers (round 4: six memsets before)
     if (all_pg) {
-    e = hipMemsetAsync(gW0, 0, (size_t)H * K * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(gb0, 0, H * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(gW1, 0, (size_t)H * H * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(gb1, 0, H * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(gW2, 0, (size_t)K * H * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(gb2, 0, K * sizeof(float), s);
+        void* const bufs[6] = {gW0, gb0, gW1, gb1, gW2, gb2};
+        const long bytes[6] = {(long)H * K * 4, (long)H * 4, (long)H * H * 4, (long)H * 4, (long)K * H * 4, (long)K * 4};
+        const int rc = zero_buffers(bufs, bytes, 6, s);
+        if (rc != NNS_OK) return rc;
     }
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
     hipLaunchKernelGGL(ode_mlp_bwd_kernel, dim3((mb + TB - 1) / TB), dim3(NT), kBwdLds, s, z0, W0, b0, W1, b1, W2, b2, states, grad_out,
                        grad_z0, gW0, gb0, gW1, gb1, gW2, gb2, reinterpret_cast<float*>(work), mb, K, Nt, method, dt_in);
     return check_launch(what);
@@ -1486,9 +1488,7 @@ int launch_loss_mfma(const float* coeff, const float* basis, const float* obs, d
     const int TC = rps < tcmax ? rps : tcmax;
     const int ldg = K <= 12 ? 12 : 20;
     const size_t lds = ((size_t)TC * kMfCwLd + 4 * 16 * kMfCwLd + (size_t)(TC / 16) * 4 * 16 * ldg) * sizeof(float);
-    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), s);
-    if (e == hipSuccess && ns > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), s);
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "%s: memset: %s", what, hipGetErrorString(e));
+    if (int rc = zero_grads(gcoeff, gbasis, ns, T, K, C, P, s); rc != NNS_OK) return rc;
     const dim3 grid(bx, C, ns);
 #define NNS_MF(KQ) hipLaunchKernelGGL((basis_loss_mfma_kernel<KQ, MODE>), grid, dim3(256), lds, s, coeff, basis, obs, sumsq, gcoeff, gbasis, scale, T, K, C, P, TC, rps, ns)
     if (K <= 4) NNS_MF(1); else if (K <= 8) NNS_MF(2); else if (K <= 12) NNS_MF(3); else NNS_MF(4);
@@ -1503,9 +1503,7 @@ NNS_API int nns_basis_loss_bwd_f32(const float* coeff, const float* basis, const
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_bwd: C must be <= 65535");
     if (int rc = launch_loss_mfma<1>(coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P, S(stream), "basis_loss_bwd"); rc != 1) return rc;
     const LossGeom g = loss_geom(T, K, C, P);
-    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
-    if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_bwd: memset: %s", hipGetErrorString(e));
+    if (int rc = zero_grads(gcoeff, gbasis, g.nsplit, T, K, C, P, S(stream)); rc != NNS_OK) return rc;
     launch_loss<1>(g, S(stream), coeff, basis, obs, nullptr, gcoeff, gbasis, scale, T, K, C, P);
     return check_launch("basis_loss_bwd");
 }
@@ -1520,9 +1518,7 @@ NNS_API int nns_basis_loss_fused_f32(const float* coeff, const float* basis, con
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_loss_fused: C must be <= 65535");
     if (int rc = launch_loss_mfma<3>(coeff, basis, obs, sumsq, gcoeff, gbasis, 1.f, T, K, C, P, S(stream), "basis_loss_fused"); rc != 1) return rc;
     const LossGeom g = loss_geom(T, K, C, P);
-    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
-    if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_loss_fused: memset: %s", hipGetErrorString(e));
+    if (int rc = zero_grads(gcoeff, gbasis, g.nsplit, T, K, C, P, S(stream)); rc != NNS_OK) return rc;
     launch_loss<3>(g, S(stream), coeff, basis, obs, sumsq, gcoeff, gbasis, 1.f, T, K, C, P);
     return check_launch("basis_loss_fused");
 }
@@ -1535,9 +1531,7 @@ NNS_API int nns_basis_expand_bwd_f32(const float* coeff, const float* basis, con
     if (C > 65535) return fail(NNS_ERR_UNSUPPORTED, "basis_expand_bwd: C must be <= 65535");
     if (int rc = launch_loss_mfma<2>(coeff, basis, grad_pred, nullptr, gcoeff, gbasis, 1.f, T, K, C, P, S(stream), "basis_expand_bwd"); rc != 1) return rc;
     const LossGeom g = loss_geom(T, K, C, P);
-    hipError_t e = hipMemsetAsync(gcoeff, 0, (size_t)T * K * C * sizeof(float), S(stream));
-    if (e == hipSuccess && g.nsplit > 1) e = hipMemsetAsync(gbasis, 0, (size_t)K * C * P * sizeof(float), S(stream));
-    if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "basis_expand_bwd: memset: %s", hipGetErrorString(e));
+    if (int rc = zero_grads(gcoeff, gbasis, g.nsplit, T, K, C, P, S(stream)); rc != NNS_OK) return rc;
     launch_loss<2>(g, S(stream), coeff, basis, grad_pred, nullptr, gcoeff, gbasis, 1.f, T, K, C, P);
     return check_launch("basis_expand_bwd");
 }

@@ -31,6 +31,9 @@ inline int check_launch(const char* what) {
     return NNS_OK;
 }
 
+// bufs[i][0 .. bytes[i]) = 0 for every i, ONE launch per 24 buffers (csrc/optim_kernels.hip); entries with bytes <= 0 are skipped
+int zero_buffers(void* const* bufs, const long* bytes, int count, hipStream_t s);
+
 inline bool field_args_ok(int batch, int nx, int ny) { return batch >= 1 && nx >= 3 && ny >= 3; }
 
 constexpr int kWave = 64;          // CDNA4 wavefront

@@ -89,6 +89,7 @@ _SINGLE = {
     'nns_basis_loss_fwd_f32': [_P] * 4 + [_I] * 4 + [_P],
     'nns_basis_loss_bwd_f32': [_P] * 3 + [C.c_float] + [_P] * 2 + [_I] * 4 + [_P],
     'nns_basis_loss_fused_f32': [_P] * 6 + [_I] * 4 + [_P],
+    'nns_adam_step_f32': [_PP] * 4 + [C.POINTER(C.c_long), _I] + [_D] * 5 + [_L, _I, _P],
     'nns_pinn_workspace_bytes': [],
     'nns_pinn_assemble_f32': [_P] * 9 + [_I, _L, _P],
     'nns_pinn_loss_f32': [_P] * 3 + [_L, _P, _D, _D, _D, _P, _P],

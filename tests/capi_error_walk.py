@@ -117,6 +117,10 @@ expect('pinn assemble one prev field', L.nns_pinn_assemble_f32(P, P, P, P, P, P,
 expect('pinn assemble misaligned workspace', L.nns_pinn_assemble_f32(P, P, P, P, P, P, None, None, P + 4, 2, 64, None), INVALID)
 expect('pinn loss n = 0', L.nns_pinn_loss_f32(P, P, P, 0, P, 0.0, 1.0, 1.0, P, None), INVALID)
 expect('pinn combine target without fields', L.nns_pinn_combine_f32(P, P, P, None, None, None, P, P, P, 1.0, 1.0, P, 1, 64, None), INVALID)
+one = (C.c_void_p * 1)(P)
+expect('adam step = 0', L.nns_adam_step_f32(one, one, one, one, (C.c_long * 1)(8), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 0, None), INVALID)
+expect('adam beta1 = 1', L.nns_adam_step_f32(one, one, one, one, (C.c_long * 1)(8), 1, 1e-3, 1.0, 0.999, 1e-8, 0.0, 1, 0, None), INVALID)
+expect('adam NULL state', L.nns_adam_step_f32(one, one, (C.c_void_p * 1)(None), one, (C.c_long * 1)(8), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 0, None), INVALID)
 expect('coarsen agg', L.nns_coarsen_f32(P, P, P, P, P, P, 2, 8, 8, 3, 3, 2, None), (INVALID, UNSUPPORTED))
 expect('cheb_gemm M=0', L.nns_cheb_gemm_f64(P, 4, 0, P, 4, 0, P, 4, 0, 4, 4, 1.0, 0.0, 1, None), (INVALID, UNSUPPORTED))
 expect('rfft2 nx=48', L.nns_spec_rfft2_f32(P, P, 1, 48, 64, None), (INVALID, UNSUPPORTED))

@@ -189,7 +189,7 @@ def test_physics_informed_loss_head_matches_the_oracle(case, gpu_device):
         t3[0].backward()
         g = o.grad.cpu().numpy()
         g = g.reshape(3, B, n, n).transpose(1, 0, 2, 3) if cm else g
-        return [float(x) for x in t3], g, o
+        return [float(x.detach()) for x in t3], g, o
 
     got, grad, _ = run()
     for a, b in zip(got, want[:3]):

@@ -521,3 +521,36 @@ def test_pixel_mlp_backward_config3_full_shape_properties(gpu_device):
     ref_gx = ON.pixel_mlp_backward([w.cpu().double() for w in Ws], [b.cpu().double() for b in bs], xs.cpu().double(), gs.cpu().double(), bf16=True)[0]
     got = gx[11].reshape(3, -1)[:, idx].reshape(1, 3, 64, 64)
     assert rel_l2(got.cpu().numpy(), ref_gx.numpy()) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('weight_decay,maximize', [(0.0, False), (0.01, False), (0.0, True)])
+def test_adam_step_matches_torch_adam(weight_decay, maximize, gpu_device):
+    """nns.optim.Adam (nns_adam_step_f32: ONE launch over all parameter tensors) against torch.optim.Adam -- the optimiser of the reference's
+    training loops (spectral_ode.py:171,189) -- over six steps on tensors of awkward sizes (scalar tails, a 4-byte-aligned view, an empty
+    tensor, more tensors than one launch table holds), and state_dict interchange in both directions."""
+    import nns.optim as nns_optim
+    torch.manual_seed(3)
+    base = torch.randn(10007, device='cuda')
+    shapes = [(1,), (3, 5), (128, 30), (2049,), (0,), (64, 64, 3)] + [(7,)] * 24
+    a = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    base2 = base.clone()
+    a.append(torch.nn.Parameter(base[1:4098])), b.append(torch.nn.Parameter(base2[1:4098]))       # contiguous, 4 bytes past a 16-byte boundary
+    assert b[-1].data_ptr() % 16 == 4
+    oa = torch.optim.Adam(a, lr=1e-2, weight_decay=weight_decay, maximize=maximize)
+    ob = nns_optim.Adam(b, lr=1e-2, weight_decay=weight_decay, maximize=maximize)
+    for step in range(6):
+        gs = [torch.randn_like(p) * (10.0 ** (step - 3)) for p in a]
+        for p, q, g in zip(a, b, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(), ob.step()
+        for p, q in zip(a, b):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (step, p.shape, (p - q).abs().max().item())
+        if step == 2:                                               # swap the states through state_dict(): each class continues the other's run
+            sa, sb = oa.state_dict(), ob.state_dict()
+            oa.load_state_dict(sb), ob.load_state_dict(sa)
+    for p, q in zip(a, b):
+        sa, sb = oa.state[p], ob.state[q]
+        assert float(sa['step']) == float(sb['step']) == 6.0
+        assert torch.allclose(sa['exp_avg'], sb['exp_avg'], rtol=2e-6, atol=1e-9) and torch.allclose(sa['exp_avg_sq'], sb['exp_avg_sq'], rtol=2e-6, atol=1e-12)

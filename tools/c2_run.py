@@ -5,11 +5,12 @@ for p in (ROOT, os.path.join(ROOT, 'neural-navier-stokes_amd')):
     sys.path.insert(0, p)
 import torch
 from nns.neural_spectral.spectral_ode import PDEFunc
+import nns.optim as nns_optim
 K, n, nt = 10, 128, 100
 m = PDEFunc(K, n, n).cuda()
 obs = torch.randn(nt, 1, 3, n, n, device='cuda')
 t = torch.arange(nt, device='cuda') + 1
-opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+opt = nns_optim.Adam(m.parameters(), lr=1e-3)
 def it():
     opt.zero_grad()
     m.loss(obs[0], t, obs).backward()

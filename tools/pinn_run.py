@@ -6,6 +6,7 @@ for p in (ROOT, os.path.join(ROOT, 'neural-navier-stokes_amd')):
 import numpy as np
 import torch
 from nns.periodic import ResidualEngine
+import nns.optim as nns_optim
 from nns.synthetic import residual_inputs
 from nns.neural_spectral.physics_informed import FieldStepper, train_step
 n = 512
@@ -17,7 +18,7 @@ target = torch.as_tensor(np.stack([np.tile(a, (4, 1, 1)) for a in ri[:3]], axis=
 if layout == 'cm':
     state, target = state.transpose(0, 1).contiguous(), target.transpose(0, 1).contiguous()
 stepper = FieldStepper(8, 64).cuda()
-opt = torch.optim.Adam(stepper.parameters(), lr=1e-4)
+opt = nns_optim.Adam(stepper.parameters(), lr=1e-4)
 eng = ResidualEngine(n, n, 1e-3, 1.0, 2 * np.pi / 1000, backend=backend)
 fused = os.environ.get('NNS_PINN_FUSED', '1') != '0'
 for _ in range(3): out = train_step(stepper, eng, opt, state, target, lam=0.1, layout=layout, fused=fused)
