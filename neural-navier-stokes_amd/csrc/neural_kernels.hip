@@ -251,13 +251,18 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
     // ADJACENT lanes and meet in three DPP adds, after which all eight hold F and keep the coefficient's RK state redundantly -- no partial-sum
     // array, no fourth barrier (round 3; s_memtime: layer 3 390 + update 430 of an evaluation's 2200 cycles before)
     const int g3 = t & 7, n3 = 8 * (t >> 6) + ((t >> 3) & 7);
-    float w0[KP / 2], w1[H / 2], w2[16];
+    // Round 4: the dot products run on v_pk_fma_f32 -- weights, activations and partial sums as register PAIRS (even element, odd element), so a
+    // thread issues half the vector instructions per evaluation (a lone wave per SIMD issues one every ~5 cycles: the FMA count WAS the time)
+    using f2 = float __attribute__((ext_vector_type(2)));
+    f2 w0[KP / 4], w1[H / 4], w2[8];
 #pragma unroll
-    for (int j = 0; j < KP / 2; ++j) { const int jj = KP / 2 * half + j; w0[j] = jj < K ? W0[(size_t)n * K + jj] : 0.f; }
+    for (int j = 0; j < KP / 2; ++j) { const int jj = KP / 2 * half + j; w0[j / 2][j & 1] = jj < K ? W0[(size_t)n * K + jj] : 0.f; }
 #pragma unroll
-    for (int j = 0; j < H / 2; ++j) w1[j] = W1[(size_t)n * H + H / 2 * half + j];
+    for (int j = 0; j < H / 2; ++j) w1[j / 2][j & 1] = W1[(size_t)n * H + H / 2 * half + j];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w2[j] = n3 < K ? W2[(size_t)n3 * H + 16 * g3 + j] : 0.f;
+    for (int j = 0; j < 16; ++j) w2[j / 2][j & 1] = n3 < K ? W2[(size_t)n3 * H + 16 * g3 + j] : 0.f;
+    auto lo = [](const float4& v) { return f2{v.x, v.y}; };
+    auto hi = [](const float4& v) { return f2{v.z, v.w}; };
     const float bias0 = half == 0 ? b0[n] : 0.f, bias1 = half == 0 ? b1[n] : 0.f;
     const float bias2 = n3 < K ? b2[n3] : 0.f;
     float y = n3 < K ? z0[(size_t)row * K + n3] : 0.f, acc = 0.f;       // RK state of coefficient n3 (the same in the eight lanes of its group)
@@ -287,19 +292,19 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
             if (timed) tq[0] = clock64();
 #endif
             {   // layer 1: K -> 128, ReLU
-                float a0 = bias0, a1 = 0.f;
+                f2 a0 = {bias0, 0.f}, a1 = {0.f, 0.f};
                 const float* x = S + KP / 2 * half;
                 float4 xv[KP / 8];                                         // every read in flight before the first FMA (see layer 2)
 #pragma unroll
                 for (int j = 0; j < KP / 8; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < KP / 2; j += 8) {
-                    const float4 x0 = xv[j / 4], x1 = xv[j / 4 + 1];
-                    a0 = fmaf(w0[j], x0.x, a0); a0 = fmaf(w0[j + 1], x0.y, a0); a0 = fmaf(w0[j + 2], x0.z, a0); a0 = fmaf(w0[j + 3], x0.w, a0);
-                    a1 = fmaf(w0[j + 4], x1.x, a1); a1 = fmaf(w0[j + 5], x1.y, a1); a1 = fmaf(w0[j + 6], x1.z, a1); a1 = fmaf(w0[j + 7], x1.w, a1);
+                for (int j = 0; j < KP / 8; j += 2) {
+                    a0 = __builtin_elementwise_fma(w0[2 * j], lo(xv[j]), a0); a0 = __builtin_elementwise_fma(w0[2 * j + 1], hi(xv[j]), a0);
+                    a1 = __builtin_elementwise_fma(w0[2 * j + 2], lo(xv[j + 1]), a1); a1 = __builtin_elementwise_fma(w0[2 * j + 3], hi(xv[j + 1]), a1);
                 }
-                const float z = half_sum(a0 + a1);
+                a0 += a1;
+                const float z = half_sum(a0.x + a0.y);
                 if (half == 0) h1[n] = fmaxf(z, 0.f);
             }
             lds_barrier();
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
             if (timed) tq[1] = clock64();
 #endif
             {   // layer 2: 128 -> 128, ELU(alpha = 1); four independent chains
-                float a[4] = {bias1, 0.f, 0.f, 0.f};
+                f2 a[4] = {f2{bias1, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
                 const float* x = h1 + H / 2 * half;
                 // all sixteen broadcast reads first: left to the compiler they came two at a time, each pair waited for (lgkmcnt(1), lgkmcnt(0))
                 // -- eight exposed LDS round trips, 1200 of an evaluation's 2500 cycles (s_memtime)
@@ -316,15 +321,15 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
                 for (int j = 0; j < H / 8; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < H / 2; j += 16) {
+                for (int j = 0; j < H / 8; j += 4) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 xq = xv[j / 4 + q];
-                        a[q] = fmaf(w1[j + 4 * q], xq.x, a[q]); a[q] = fmaf(w1[j + 4 * q + 1], xq.y, a[q]);
-                        a[q] = fmaf(w1[j + 4 * q + 2], xq.z, a[q]); a[q] = fmaf(w1[j + 4 * q + 3], xq.w, a[q]);
+                        a[q] = __builtin_elementwise_fma(w1[2 * (j + q)], lo(xv[j + q]), a[q]);
+                        a[q] = __builtin_elementwise_fma(w1[2 * (j + q) + 1], hi(xv[j + q]), a[q]);
                     }
                 }
-                const float z = half_sum((a[0] + a[1]) + (a[2] + a[3]));
+                const f2 a2 = (a[0] + a[1]) + (a[2] + a[3]);
+                const float z = half_sum(a2.x + a2.y);
                 if (half == 0) h2[n] = elu1(z);
             }
             lds_barrier();
@@ -332,19 +337,19 @@ __global__ __launch_bounds__(RT) void ode_mlp_fwd_row_kernel(const float* __rest
             if (timed) tq[2] = clock64();
 #endif
             {   // layer 3: 128 -> K, an eighth of the inputs per lane; then F and the scheme's update of coefficient n3 (scheme.py:21-42)
-                float a0 = 0.f, a1 = 0.f;
+                f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
                 const float* x = h2 + 16 * g3;
                 float4 xv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const float4*>(x + 4 * j);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 16; j += 8) {
-                    const float4 x0 = xv[j / 4], x1 = xv[j / 4 + 1];
-                    a0 = fmaf(w2[j], x0.x, a0); a0 = fmaf(w2[j + 1], x0.y, a0); a0 = fmaf(w2[j + 2], x0.z, a0); a0 = fmaf(w2[j + 3], x0.w, a0);
-                    a1 = fmaf(w2[j + 4], x1.x, a1); a1 = fmaf(w2[j + 5], x1.y, a1); a1 = fmaf(w2[j + 6], x1.z, a1); a1 = fmaf(w2[j + 7], x1.w, a1);
+                for (int j = 0; j < 4; j += 2) {
+                    a0 = __builtin_elementwise_fma(w2[2 * j], lo(xv[j]), a0); a0 = __builtin_elementwise_fma(w2[2 * j + 1], hi(xv[j]), a0);
+                    a1 = __builtin_elementwise_fma(w2[2 * j + 2], lo(xv[j + 1]), a1); a1 = __builtin_elementwise_fma(w2[2 * j + 3], hi(xv[j + 1]), a1);
                 }
-                float f = a0 + a1;
+                a0 += a1;
+                float f = a0.x + a0.y;
                 auto dpp_add = [](float v, auto ctrl) { return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, false)); };
                 f = dpp_add(f, std::integral_constant<int, 0xB1>{});            // quad_perm [1,0,3,2]: lanes g3 ^ 1
                 f = dpp_add(f, std::integral_constant<int, 0x4E>{});            // quad_perm [2,3,0,1]: lanes g3 ^ 2
