@@ -23,6 +23,7 @@ def main(which='spectral_ode'):
     parser.add_argument('--n-coeffs', type=int, default=10, help='default: 10')
     parser.add_argument('--gpu-device', type=int, default=0, help='default: 0')
     parser.add_argument('--unfused-loss', action='store_true')
+    parser.add_argument('--no-graph', action='store_true', help='run every iteration eagerly instead of replaying ONE captured HIP graph of loss + backward')
     args = parser.parse_args()
     args.out_dir = '{}_{}'.format(args.out_dir, args.n_coeffs)
     if not os.path.isdir(args.out_dir):
@@ -43,18 +44,30 @@ def main(which='spectral_ode'):
     optimizer = Adam(model.parameters(), lr=1e-3)
     loss_meter, penalty_meter = mod.AverageMeter(), mod.AverageMeter()
     losses, penalties = [], []
+    loss_fn = (lambda: torch.norm(model(obs0, t) - obs, p=2)) if args.unfused_loss else (lambda: model.loss(obs0, t, obs))
+    graphed = None
+    if device != 'cpu' and not args.no_graph:
+        # the iteration runs the same kernels on the same buffers every time (the observations are fixed, :175-177): capture it once (nns/graphs.py)
+        from ..graphs import GraphedBackward
+        try:
+            graphed = GraphedBackward(model.parameters(), loss_fn)
+        except Exception as e:                                   # noqa: BLE001 -- a model whose step does not capture trains eagerly
+            print('train: HIP graph capture of the iteration failed (%r): running eagerly' % (e,))
+            for q in model.parameters():
+                q.grad = None
     for itr in range(1, args.n_iters + 1):
-        optimizer.zero_grad()
-        if args.unfused_loss:
-            loss = torch.norm(model(obs0, t) - obs, p=2)
+        if graphed is not None:
+            loss = graphed()
         else:
-            loss = model.loss(obs0, t, obs)
+            optimizer.zero_grad()
+            loss = loss_fn()
         if hasattr(model, 'diversity_penalty'):
             with torch.no_grad():
                 penalty = 1. / model.diversity_penalty()
                 penalty_meter.update(penalty.item())
                 penalties.append(penalty.item())
-        loss.backward()
+        if graphed is None:
+            loss.backward()
         optimizer.step()
         loss_meter.update(loss.item())
         losses.append(loss.item())

@@ -554,3 +554,33 @@ def test_adam_step_matches_torch_adam(weight_decay, maximize, gpu_device):
         sa, sb = oa.state[p], ob.state[q]
         assert float(sa['step']) == float(sb['step']) == 6.0
         assert torch.allclose(sa['exp_avg'], sb['exp_avg'], rtol=2e-6, atol=1e-9) and torch.allclose(sa['exp_avg_sq'], sb['exp_avg_sq'], rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_graphed_backward_replays_the_training_iteration(gpu_device):
+    """nns.graphs.GraphedBackward: loss + backward of the reference's training iteration (spectral_ode.py:178-188) captured ONCE as a HIP graph.
+    Replays follow the parameters as the optimiser moves them: six graphed steps give the losses and parameters of six eager steps (float32
+    atomics in the gradient sums: 1e-5), zero_grad(set_to_none=True) between steps is harmless, new observations go in through copy_."""
+    import nns.optim as nns_optim
+    from nns.graphs import GraphedBackward
+    from nns.neural_spectral.spectral_ode import PDEFunc
+    K, n, nt = 6, 64, 20
+    torch.manual_seed(0)
+    me = PDEFunc(K, n, n).cuda()
+    mg = PDEFunc(K, n, n).cuda(); mg.load_state_dict(me.state_dict())
+    obs = torch.randn(nt, 1, 3, n, n, device='cuda')
+    obs_g = obs.clone()
+    t = torch.arange(nt, device='cuda') + 1
+    oe, og = nns_optim.Adam(me.parameters(), lr=1e-2), nns_optim.Adam(mg.parameters(), lr=1e-2)
+    gb = GraphedBackward(mg.parameters(), lambda: mg.loss(obs_g[0], t, obs_g))
+    for step in range(6):
+        if step == 3:                                   # new data: into the tensors the graph reads
+            obs = obs * 0.5 + 0.1
+            obs_g.copy_(obs)
+        oe.zero_grad()
+        le = me.loss(obs[0], t, obs); le.backward(); oe.step()
+        og.zero_grad(set_to_none=True)
+        lg = gb(); og.step()
+        assert abs(float(le) - float(lg)) <= 1e-5 * abs(float(le)), (step, float(le), float(lg))
+    for a, b in zip(me.parameters(), mg.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), (a - b).abs().max().item()
