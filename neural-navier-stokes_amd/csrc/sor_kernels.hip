@@ -23,7 +23,8 @@ namespace {
 
 constexpr int kSorThreads = 1024;                 // 16 waves
 constexpr int kSorWaves = kSorThreads / kWave;
-constexpr int kSorHdr = 256;                       // LDS header: per-sweep errs + stop flag
+constexpr int kSorBatch = 128;                     // sweeps per speculative batch at most (row-per-lane pipeline; the LDS-exchange pipeline runs kSorWaves)
+constexpr int kSorHdr = kSorBatch * 8 + 128;       // LDS header: per-sweep errs + stop flag
 
 template <typename T>
 struct SorK { T dx2, dy2, den, beta, omb, tol; };
@@ -59,13 +60,96 @@ __device__ __forceinline__ void sor_batch(T* pw, const T* cw, int nx, int ny, in
     __syncthreads();
 }
 
+// Round 4: the same pipeline with every ROW of the grid owned by one LANE (nx - 2 <= 64: the reference's 51 x 51 and 64 x 64 grids).
+//   * Lane i - 1 marches along row i, one column per front, so both same-sweep neighbours of a point are already in registers: p[i][j-1] is the
+//     lane's own previous result, p[i-1][j] the previous result of the lane before it (one DPP rotate).  What is left to LDS are the PREVIOUS
+//     sweep's values (p[i][j+1], p[i+1][j], p[i][j]) and C -- and with a lag of three fronts between consecutive sweeps instead of two those were
+//     written two steps ago, so they are requested a step AHEAD and the load latency leaves the critical path.
+//   * A front of one sweep keeps on average HALF the lanes of its wave busy, and the kernel is bound by vector-instruction issue on its one CU
+//     (16 waves x ~45 instructions, 28 of them float64, per step on four SIMDs: ~800 cycles per step measured).  A lane that has finished its row
+//     of sweep s therefore goes straight on to the same row of sweep s + 16 (the wave's next one): the rows still open in sweep s are the HIGH
+//     ones, those already open in sweep s + 16 the LOW ones -- complementary when the two are ny - 2 fronts apart -- so every lane computes a
+//     point in every step and 49 sweeps take 3 (ny - 2) + nfronts steps instead of 4 (nfronts + 45).
+// Same operations on the same operands in the same order as sor_batch: bitwise the same p, errs and sweep count (tools/sor_ab.py).
+#ifndef NNS_SOR_ROWS
+#define NNS_SOR_ROWS 1
+#endif
+constexpr int kSorLag = 3;
+
+__device__ __forceinline__ float lane_before(float x) {       // lane l <- lane l - 1 (wave rotate right by one)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double lane_before(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x13C, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x13C, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// Sweep s runs on wave s % 16 and starts (its front 0) at step  T_s = (s / 16) P + (s % 16) kSorLag,  P = max(16 kSorLag, ny - 2, nx - 2):
+// consecutive sweeps are >= kSorLag steps apart, consecutive sweeps of ONE wave P steps -- a lane needs ny - 2 of them for its row, and
+// P >= nx - 2 keeps a lane's finished-row maximum in place until its wave has reduced that sweep's error.
+template <typename T>
+__device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int ny, int nsw, const SorK<T>& k, T* errs) {
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int i = lane + 1, row = i * ny, ncol = ny - 2;
+    const bool has_row = i <= nx - 2;
+    const int nfronts = nx + ny - 5;
+    const int P = max(kSorWaves * kSorLag, max(ncol, nx - 2));
+    const int nsteps = ((nsw - 1) / kSorWaves) * P + ((nsw - 1) % kSorWaves) * kSorLag + nfronts + 1;       // the last step reduces the last sweep's error
+    // this lane's clock: pos < 0 waiting, 0 <= pos < ncol column pos + 1 of sweep `sweep`, then idle until pos == P starts the wave's next sweep
+    int pos = -(i - 1) - wave * kSorLag, sweep = wave;
+    // the wave's clock for the error reductions: sweep `esweep` is complete when epos reaches 0
+    int epos = -wave * kSorLag - nfronts, esweep = wave;
+    T emax = (T)0, edone = (T)0, own = (T)0;
+    T qe = (T)0, qs = (T)0, qo = (T)0, qc = (T)0, qn = (T)0, qw = (T)0;       // the operands of this lane's next point, requested a step ahead
+    auto request = [&](int ps, int sw) {
+        if (has_row && sw < nsw && ps >= 0 && ps < ncol) {
+            const int c = row + ps + 1;
+            qe = pw[c + 1]; qs = pw[c + ny]; qo = pw[c]; qc = cw[c]; qn = pw[c - ny]; qw = pw[c - 1];
+        }
+    };
+    request(pos, sweep);
+    for (int t = 0; t < nsteps; ++t) {
+        if (epos == 0) {                                                       // wave-uniform: every row of sweep esweep is done, no lane has finished another since
+            if (esweep < nsw) {
+                T e = edone;
+                for (int o = kWave / 2; o > 0; o >>= 1) e = nanmax<T>(e, __shfl_down(e, o));
+                if (lane == 0) errs[esweep] = e;
+            }
+            epos = -P; esweep += kSorWaves;
+        }
+        const T north = lane_before(own);                                      // p[i-1][j] of THIS sweep (before any lane moves on)
+        if (has_row && sweep < nsw && pos >= 0 && pos < ncol) {
+            const T n_ = i == 1 ? qn : north, w_ = pos == 0 ? qw : own;          // boundary values come from the grid, interior ones from registers
+            const T nw = (k.beta * (k.dy2 * qs + k.dy2 * n_ + k.dx2 * qe + k.dx2 * w_ - qc) / k.den + k.omb * qo);        // :193-196
+            pw[row + pos + 1] = nw;
+            own = nw;
+            emax = nanmax<T>(emax, fabs(nw - qo));
+            if (pos == ncol - 1) { edone = emax; emax = (T)0; }                // the row is finished: its maximum waits for the wave's reduction
+        }
+        ++pos; ++epos;
+        if (pos == P) { pos = 0; sweep += kSorWaves; }
+        request(pos, sweep);
+        __syncthreads();
+    }
+    __syncthreads();
+}
+
+template <bool IN_LDS> __device__ __forceinline__ bool sor_rows_path(int nx) { return IN_LDS && NNS_SOR_ROWS && nx - 2 <= kWave; }
+
+template <typename T, bool IN_LDS>
+__device__ __forceinline__ void sor_run_batch(T* pw, const T* cw, int nx, int ny, int nsw, const SorK<T>& k, T* errs) {
+    if (sor_rows_path<IN_LDS>(nx)) sor_batch_rows<T>(pw, cw, nx, ny, nsw, k, errs);
+    else sor_batch<T>(pw, cw, nx, ny, nsw, k, errs);
+}
+
 template <typename T, bool IN_LDS>
 __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, const T* __restrict__ C, T* __restrict__ info,
                                                            T* __restrict__ snap, int nx, int ny, int max_sweeps, SorK<T> k) {
     // all LDS in the dynamic region (16-byte aligned carve): [errs 16 x 8 B][stop][pad to 256][p][C]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* errs = reinterpret_cast<T*>(smem_raw);
-    int* s_stop_p = reinterpret_cast<int*>(smem_raw + 128);
+    int* s_stop_p = reinterpret_cast<int*>(smem_raw + kSorBatch * 8);
     const int n = nx * ny, tid = threadIdx.x;
     T* pg = p + (size_t)blockIdx.x * n;
     const T* cg = C + (size_t)blockIdx.x * n;
@@ -82,10 +166,10 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
     int done = 0;
     T err = (T)1;                                                     // :183
     while (done < max_sweeps) {
-        const int nsw = min(kSorWaves, max_sweeps - done);
+        const int nsw = min(sor_rows_path<IN_LDS>(nx) ? kSorBatch : kSorWaves, max_sweeps - done);
         for (int c = tid; c < n; c += kSorThreads) sg[c] = pw[c];      // snapshot for an exact early stop
         __syncthreads();
-        sor_batch<T>(pw, cw, nx, ny, nsw, k, errs);
+        sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, nsw, k, errs);
         if (tid == 0) {
             int stop = -1;
             for (int s = 0; s < nsw; ++s) if (!(errs[s] > k.tol)) { stop = s; break; }    // loop runs while err > tol
@@ -99,7 +183,7 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
             __syncthreads();
             for (int c = tid; c < n; c += kSorThreads) pw[c] = sg[c];
             __syncthreads();
-            sor_batch<T>(pw, cw, nx, ny, stop + 1, k, errs);
+            sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, stop + 1, k, errs);
             err = e_keep;
         } else {
             err = errs[stop];
