@@ -16,6 +16,7 @@
 // grid is restored from the snapshot taken at the start of the batch and exactly that many
 // sweeps are replayed.  Compiled with -ffp-contract=off (reference operation order).
 #include "nns_common.h"
+#include <cmath>
 
 using namespace nns;
 
@@ -27,7 +28,7 @@ constexpr int kSorBatch = 128;                     // sweeps per speculative bat
 constexpr int kSorHdr = kSorBatch * 8 + 128;       // LDS header: per-sweep errs + stop flag
 
 template <typename T>
-struct SorK { T dx2, dy2, den, beta, omb, tol; };
+struct SorK { T dx2, dy2, den, beta, omb, tol, rcp; };       // rcp: RN(1 / den) where div_den's short form applies, else 0 (set by sor())
 
 template <typename T>
 __device__ __forceinline__ T nanmax(T a, T b) { return (b > a || b != b) ? b : a; }
@@ -74,6 +75,9 @@ __device__ __forceinline__ void sor_batch(T* pw, const T* cw, int nx, int ny, in
 #ifndef NNS_SOR_ROWS
 #define NNS_SOR_ROWS 1
 #endif
+#ifndef NNS_SOR_TIMING
+#define NNS_SOR_TIMING 0            // 1: the row-per-lane pipeline prints the cycles of a step's parts (s_memtime stamps, waves 0 and 7)
+#endif
 constexpr int kSorLag = 3;
 
 __device__ __forceinline__ float lane_before(float x) {       // lane l <- lane l - 1 (wave rotate right by one)
@@ -88,10 +92,33 @@ __device__ __forceinline__ double lane_before(double x) {
 // Sweep s runs on wave s % 16 and starts (its front 0) at step  T_s = (s / 16) P + (s % 16) kSorLag,  P = max(16 kSorLag, ny - 2, nx - 2):
 // consecutive sweeps are >= kSorLag steps apart, consecutive sweeps of ONE wave P steps -- a lane needs ny - 2 of them for its row, and
 // P >= nx - 2 keeps a lane's finished-row maximum in place until its wave has reduced that sweep's error.
+// x / k.den for the row-per-lane pipeline.  The divisor is one constant per solve, so the IEEE quotient can be had from its correctly rounded
+// reciprocal y = RN(1 / den) (computed on the host) by Markstein's correction  q = RN(x y), r = x - q den (exact in an FMA), RN(q + r y)  -- three
+// instructions where the compiler's division is thirteen (v_div_scale x 2, v_rcp, two Newton steps, v_div_fmas, v_div_fixup), a quarter of the
+// point update this issue-bound kernel is made of.  Used only where no intermediate can leave the normal range (|x| and den guarded; zeros,
+// infinities and NaNs take the plain division: -0 / den must stay -0); tools/fastdiv_check.hip compared it with `/` BITWISE on 1.4e10 random
+// operands per type over 51 divisors (the reference's grids, random ones, significands of nearly all ones): no mismatch.
+#ifndef NNS_SOR_FASTDIV
+#define NNS_SOR_FASTDIV 1
+#endif
 template <typename T>
-__device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int ny, int nsw, const SorK<T>& k, T* errs) {
+__device__ __forceinline__ T div_den(T x, const SorK<T>& k) {
+#if NNS_SOR_FASTDIV
+    constexpr T lo = sizeof(T) == 8 ? (T)1e-250 : (T)1e-25, hi = sizeof(T) == 8 ? (T)1e250 : (T)1e25;
+    const T ax = fabs(x);
+    const T q = x * k.rcp;
+    T res = ax == (T)0 ? x : fma(fma(-q, k.den, x), k.rcp, q);              // +-0 / den = +-0 (den > 0): a cavity at rest is zeros for many steps
+    if (!(k.rcp != (T)0 && ((ax >= lo && ax <= hi) || ax == (T)0))) res = x / k.den;      // rare: the wave skips it when no lane needs it
+    return res;
+#else
+    return x / k.den;
+#endif
+}
+
+template <typename T>
+__device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int ny, int pitch, int nsw, const SorK<T>& k, T* errs) {
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int i = lane + 1, row = i * ny, ncol = ny - 2;
+    const int i = lane + 1, row = i * pitch, ncol = ny - 2;
     const bool has_row = i <= nx - 2;
     const int nfronts = nx + ny - 5;
     const int P = max(kSorWaves * kSorLag, max(ncol, nx - 2));
@@ -105,11 +132,18 @@ __device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int n
     auto request = [&](int ps, int sw) {
         if (has_row && sw < nsw && ps >= 0 && ps < ncol) {
             const int c = row + ps + 1;
-            qe = pw[c + 1]; qs = pw[c + ny]; qo = pw[c]; qc = cw[c]; qn = pw[c - ny]; qw = pw[c - 1];
+            qe = pw[c + 1]; qs = pw[c + pitch]; qo = pw[c]; qc = cw[c]; qn = pw[c - pitch]; qw = pw[c - 1];
         }
     };
     request(pos, sweep);
+#if NNS_SOR_TIMING
+    long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tcomp = 0, treq = 0, tbar = 0;
+#endif
     for (int t = 0; t < nsteps; ++t) {
+#if NNS_SOR_TIMING
+        const bool timed = t >= 100 && t < 164 && blockIdx.x == 0;
+        if (timed) tq0 = clock64();
+#endif
         if (epos == 0) {                                                       // wave-uniform: every row of sweep esweep is done, no lane has finished another since
             if (esweep < nsw) {
                 T e = edone;
@@ -121,7 +155,7 @@ __device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int n
         const T north = lane_before(own);                                      // p[i-1][j] of THIS sweep (before any lane moves on)
         if (has_row && sweep < nsw && pos >= 0 && pos < ncol) {
             const T n_ = i == 1 ? qn : north, w_ = pos == 0 ? qw : own;          // boundary values come from the grid, interior ones from registers
-            const T nw = (k.beta * (k.dy2 * qs + k.dy2 * n_ + k.dx2 * qe + k.dx2 * w_ - qc) / k.den + k.omb * qo);        // :193-196
+            const T nw = (div_den<T>(k.beta * (k.dy2 * qs + k.dy2 * n_ + k.dx2 * qe + k.dx2 * w_ - qc), k) + k.omb * qo);  // :193-196
             pw[row + pos + 1] = nw;
             own = nw;
             emax = nanmax<T>(emax, fabs(nw - qo));
@@ -129,17 +163,42 @@ __device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int n
         }
         ++pos; ++epos;
         if (pos == P) { pos = 0; sweep += kSorWaves; }
+#if NNS_SOR_TIMING
+        if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tq1 = clock64(); }
+#endif
         request(pos, sweep);
+#if NNS_SOR_TIMING
+        if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tq2 = clock64(); }
+#endif
         __syncthreads();
+#if NNS_SOR_TIMING
+        if (timed) { tq3 = clock64(); tcomp += tq1 - tq0; treq += tq2 - tq1; tbar += tq3 - tq2; }
+#endif
     }
+#if NNS_SOR_TIMING
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7) && nsw > 40)
+        printf("sor rows, wave %d, mean of steps 100..163 (cycles): compute (to the store's completion) %ld, request + its wait %ld, barrier %ld\n", wave, tcomp / 64, treq / 64, tbar / 64);
+#endif
     __syncthreads();
 }
 
 template <bool IN_LDS> __device__ __forceinline__ bool sor_rows_path(int nx) { return IN_LDS && NNS_SOR_ROWS && nx - 2 <= kWave; }
+// LDS row pitch of the row-per-lane pipeline: its lanes access ONE column of consecutive rows, so a pitch of 2^k elements (the 64 x 64 grid) would
+// put a whole wave on one bank pair; an odd pitch spreads 8-byte elements over all 64 banks (4-byte ones over 32 of them at pitch = 1 mod 64 ...)
+#ifndef NNS_SOR_PITCH
+#define NNS_SOR_PITCH 0              // measured (round 4, 64 x 64 float64): even paddings change nothing (the kernel is bound by instruction issue, not by LDS banks), an ODD pitch is 3x slower (rows that are not 16-byte aligned: the adjacent-pair ds_read2_b64)
+#endif
+#ifndef NNS_SOR_PITCH_ADD
+#define NNS_SOR_PITCH_ADD -1          // developer probe: >= 0 pads every row by that many elements instead of making the pitch odd
+#endif
+__host__ __device__ inline int sor_pitch(int nx, int ny, bool in_lds) {
+    if (!(NNS_SOR_PITCH && in_lds && NNS_SOR_ROWS && nx - 2 <= kWave)) return ny;
+    return NNS_SOR_PITCH_ADD >= 0 ? ny + NNS_SOR_PITCH_ADD : (ny | 1);
+}
 
 template <typename T, bool IN_LDS>
-__device__ __forceinline__ void sor_run_batch(T* pw, const T* cw, int nx, int ny, int nsw, const SorK<T>& k, T* errs) {
-    if (sor_rows_path<IN_LDS>(nx)) sor_batch_rows<T>(pw, cw, nx, ny, nsw, k, errs);
+__device__ __forceinline__ void sor_run_batch(T* pw, const T* cw, int nx, int ny, int pitch, int nsw, const SorK<T>& k, T* errs) {
+    if (sor_rows_path<IN_LDS>(nx)) sor_batch_rows<T>(pw, cw, nx, ny, pitch, nsw, k, errs);
     else sor_batch<T>(pw, cw, nx, ny, nsw, k, errs);
 }
 
@@ -156,10 +215,12 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
     T* sg = snap + (size_t)blockIdx.x * n;
     T* pw = pg;
     const T* cw = cg;
+    const int pitch = sor_pitch(nx, ny, IN_LDS);
+    auto at = [&](int c) { return pitch == ny ? c : (c / ny) * pitch + c % ny; };      // element c of the dense grid in the working copy
     if (IN_LDS) {
         T* pl = reinterpret_cast<T*>(smem_raw + kSorHdr);
-        T* cl = pl + n;
-        for (int c = tid; c < n; c += kSorThreads) { pl[c] = pg[c]; cl[c] = cg[c]; }
+        T* cl = pl + nx * pitch;
+        for (int c = tid; c < n; c += kSorThreads) { pl[at(c)] = pg[c]; cl[at(c)] = cg[c]; }
         pw = pl; cw = cl;
         __syncthreads();
     }
@@ -167,9 +228,9 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
     T err = (T)1;                                                     // :183
     while (done < max_sweeps) {
         const int nsw = min(sor_rows_path<IN_LDS>(nx) ? kSorBatch : kSorWaves, max_sweeps - done);
-        for (int c = tid; c < n; c += kSorThreads) sg[c] = pw[c];      // snapshot for an exact early stop
+        for (int c = tid; c < n; c += kSorThreads) sg[c] = pw[at(c)];  // snapshot for an exact early stop
         __syncthreads();
-        sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, nsw, k, errs);
+        sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, pitch, nsw, k, errs);
         if (tid == 0) {
             int stop = -1;
             for (int s = 0; s < nsw; ++s) if (!(errs[s] > k.tol)) { stop = s; break; }    // loop runs while err > tol
@@ -181,9 +242,9 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
         if (stop < nsw - 1) {                                          // overshoot: restore and replay stop+1 sweeps
             const T e_keep = errs[stop];
             __syncthreads();
-            for (int c = tid; c < n; c += kSorThreads) pw[c] = sg[c];
+            for (int c = tid; c < n; c += kSorThreads) pw[at(c)] = sg[c];
             __syncthreads();
-            sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, stop + 1, k, errs);
+            sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, pitch, stop + 1, k, errs);
             err = e_keep;
         } else {
             err = errs[stop];
@@ -192,7 +253,7 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
         break;
     }
     __syncthreads();
-    if (IN_LDS) for (int c = tid; c < n; c += kSorThreads) pg[c] = pw[c];
+    if (IN_LDS) for (int c = tid; c < n; c += kSorThreads) pg[c] = pw[at(c)];
     if (tid == 0) { info[2 * blockIdx.x] = (T)done; info[2 * blockIdx.x + 1] = err; }
 }
 
@@ -201,10 +262,15 @@ int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double
         int max_sweeps, hipStream_t s) {
     if (!p || !C || !info || !work || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_sor: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
-    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
-    const size_t lds = kSorHdr + 2 * (size_t)nx * ny * sizeof(T);
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol, (T)0};
+    {   // the short division needs a divisor well inside the normal range (its reciprocal and every x - q den too)
+        const double ad = std::fabs((double)k.den), dlo = sizeof(T) == 8 ? 1e-50 : 1e-10, dhi = sizeof(T) == 8 ? 1e50 : 1e10;
+        if (ad >= dlo && ad <= dhi && k.den > (T)0) k.rcp = (T)1 / k.den;
+    }
+    size_t lds = kSorHdr + 2 * (size_t)nx * sor_pitch(nx, ny, true) * sizeof(T);
+    if (lds > 150 * 1024) lds = kSorHdr + 2 * (size_t)nx * ny * sizeof(T);        // (cannot happen for nx <= 66; keeps the two sides of the choice in one place)
     T* snap = reinterpret_cast<T*>(work);
-    if (lds <= 150 * 1024) {
+    if (kSorHdr + 2 * (size_t)nx * ny * sizeof(T) <= 150 * 1024 && lds <= 150 * 1024) {
         static bool attr = false;                     // set once to the largest size used (keeps the launch path free of
         if (!attr) {                                  // non-stream API calls, e.g. under hipGraph capture)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sor_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -351,7 +417,7 @@ template <typename T>
 int sor_rb_halfsweep(T* p, const T* C, void* err_bits, int nxl, int ny, int gi0, int colour, double dx, double dy, double beta, hipStream_t s) {
     if (!p || !C || !err_bits || nxl < 3 || ny < 3 || (colour != 0 && colour != 1) || gi0 < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack_halfsweep: bad args (nxl=%d ny=%d gi0=%d colour=%d)", nxl, ny, gi0, colour);
-    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)0};
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)0, (T)0};
     launch_halfsweep<T>(p, C, static_cast<typename BitsOf<T>::U*>(err_bits), nullptr, 0, 1, nxl, ny, gi0, colour, k, s);
     return check_launch("fd_sor_redblack_halfsweep");
 }
@@ -364,7 +430,7 @@ int sor_rb_halfsweep_gated(T* p, const T* C, void* err_bits, const void* prev_bi
                            double dx, double dy, double beta, hipStream_t s) {
     if (!p || !C || !err_bits || !prev_bits || nxl < 3 || ny < 3 || (colour != 0 && colour != 1) || gi0 < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack_halfsweep_gated: bad args (nxl=%d ny=%d gi0=%d colour=%d)", nxl, ny, gi0, colour);
-    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol, (T)0};
     using U = typename BitsOf<T>::U;
     launch_halfsweep<T>(p, C, static_cast<U*>(err_bits), static_cast<const U*>(prev_bits), 0, 1, nxl, ny, gi0, colour, k, s);
     return check_launch("fd_sor_redblack_halfsweep_gated");
@@ -396,7 +462,7 @@ template <typename T>
 int sor_redblack(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double dx, double dy, double beta, double tol, int max_sweeps, hipStream_t s) {
     if (!p || !C || !info || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_sor_redblack: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
-    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol};
+    SorK<T> k{(T)(dx * dx), (T)(dy * dy), (T)(2 * (dx * dx) + 2 * (dy * dy)), (T)beta, (T)(1 - beta), (T)tol, (T)0};
     if (rb_fits_lds(nx, ny, sizeof(T))) {
         const size_t lds = 2 * (size_t)nx * ny * sizeof(T);
         static bool attr = false;
