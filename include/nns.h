@@ -174,6 +174,21 @@ int nns_coarsen_f32(const float* u, const float* v, const float* p, float* cu, f
 int nns_coarsen_f64(const double* u, const double* v, const double* p, double* cu, double* cv, double* cp, int nt, int nx, int ny,
                     int agg_x, int agg_y, int jfill, void* stream);
 
+/* step (:212-234) of the EXPLICIT method as ONE launch, one workgroup per grid: _explicit_predictor_step, the velocity boundary lists, _get_pressure
+ * (right-hand side + the lexicographic SOR solve, tol / max_sweeps as nns_fd_sor_*), the pressure boundary list, _correction_step -- bitwise the
+ * sequence nns_fd_predictor_explicit(_corrected) / nns_bc_apply x 2 / nns_fd_pressure_rhs / nns_fd_sor / nns_bc_apply / nns_fd_correction (the same
+ * per-point functions).  p is updated in place (as the reference mutates it) and also written to p_copy when that is not NULL (a trajectory slot);
+ * u_out, v_out receive the new velocities (they hold the intermediate ones on the way: they must not alias an input field); info [batch][2] =
+ * (sweeps, last err); work: nns_fd_sor_workspace(batch, nx, ny, elem) bytes.  Applies when p and its right-hand side fit one workgroup's LDS
+ * (nns_fd_step_explicit_fits: 64 x 64 float64, 96 x 96 float32 and below); NNS_ERR_UNSUPPORTED otherwise: use the separate calls. */
+int nns_fd_step_explicit_fits(int nx, int ny, int elem_size);
+int nns_fd_step_explicit_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* p, const nns_bc_list* u_bc, const nns_bc_list* v_bc,
+                             const nns_bc_list* p_bc, float* u_out, float* v_out, float* p_copy, float* info, void* work, int batch, int nx, int ny,
+                             double dt, double dx, double dy, double rho, double nu, double beta, double tol, int max_sweeps, int corrected, void* stream);
+int nns_fd_step_explicit_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* p, const nns_bc_list* u_bc, const nns_bc_list* v_bc,
+                             const nns_bc_list* p_bc, double* u_out, double* v_out, double* p_copy, double* info, void* work, int batch, int nx, int ny,
+                             double dt, double dx, double dy, double rho, double nu, double beta, double tol, int max_sweeps, int corrected, void* stream);
+
 /* _correction_step (:204-210): u = u* - dt/(2dx) d0x p, v = v* - dt/(2dy) d0y p; edges from u*. */
 int nns_fd_correction_f32(const float* ui, const float* vi, const float* p, float* u, float* v,
                           int batch, int nx, int ny, double dt, double dx, double dy, void* stream);

@@ -8,8 +8,10 @@
 // field; the i+-1 / j+-1 re-reads are served by L1/L2.  Algorithmic bytes per point are listed
 // at each kernel (T = sizeof element).
 #include "nns_common.h"
+#include "fd_device.h"
 
 using namespace nns;
+using namespace nns::fd;
 
 namespace {
 
@@ -20,41 +22,6 @@ inline dim3 grid2d(int batch, int nx, int ny) { return dim3((ny + kTX - 1) / kTX
 // ------------------------------------------------------------------------------------------
 // Boundary conditions  (src/boundary.py:34-48, :56-86)
 // ------------------------------------------------------------------------------------------
-// One BC of the list applied by all threads of a block to the grid at A (global or LDS).
-template <typename T, typename P>
-__device__ __forceinline__ void bc_apply_one(P A, int nx, int ny, int kind, int side, T value, T dx, T dy,
-                                             int tid, int nthreads) {
-    if (side == NNS_SIDE_LEFT || side == NNS_SIDE_RIGHT) {
-        const int i = side == NNS_SIDE_LEFT ? 0 : nx - 1;
-        const int in = side == NNS_SIDE_LEFT ? 1 : nx - 2;
-        for (int j = tid; j < ny; j += nthreads) {
-            T r;
-            if (kind == NNS_BC_DIRICHLET) r = value;
-            else r = side == NNS_SIDE_LEFT ? A[(size_t)in * ny + j] - dx * value : A[(size_t)in * ny + j] + dx * value;
-            A[(size_t)i * ny + j] = r;
-        }
-    } else {
-        const int j = side == NNS_SIDE_BOTTOM ? 0 : ny - 1;
-        const int jn = side == NNS_SIDE_BOTTOM ? 1 : ny - 2;
-        for (int i = tid; i < nx; i += nthreads) {
-            T r;
-            if (kind == NNS_BC_DIRICHLET) r = value;
-            else r = side == NNS_SIDE_BOTTOM ? A[(size_t)i * ny + jn] - dy * value : A[(size_t)i * ny + jn] + dy * value;
-            A[(size_t)i * ny + j] = r;
-        }
-    }
-}
-
-// The whole list in list order (later entries win at corners, and a Neumann entry may read a
-// corner an earlier entry wrote): one workgroup per grid, a barrier between entries.
-template <typename T, typename P>
-__device__ __forceinline__ void bc_apply_list(P A, int nx, int ny, const BcListDev<T>& bcs, int tid, int nthreads) {
-    for (int k = 0; k < bcs.n; ++k) {
-        bc_apply_one<T>(A, nx, ny, bcs.kind[k], bcs.side[k], bcs.value[k], bcs.dx[k], bcs.dy[k], tid, nthreads);
-        __syncthreads();
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void bc_apply_kernel(T* A, int nx, int ny, BcListDev<T> bcs) {
     T* g = A + (size_t)blockIdx.x * nx * ny;
@@ -75,9 +42,6 @@ int bc_apply(T* A, int batch, int nx, int ny, const nns_bc_list* h, hipStream_t 
 // chorin_fd._explicit_predictor_step  (src/chorin_fd/simulate.py:63-91)
 // algorithmic traffic: read un,vn,un1,vn1 + write ui,vi = 6T B/pt
 // ------------------------------------------------------------------------------------------
-template <typename T>
-struct PredK { T dt, two_dx, two_dy, dx2, dy2, dt_nu; };
-
 // CORRECT = true: the build's "fixed y-advection" option (oracle:
 // explicit_predictor_corrected): v d/dy differences along y.  false: the reference's form (x-difference twice).
 template <typename T, bool CORRECT>
@@ -87,30 +51,8 @@ __global__ __launch_bounds__(kTX) void predictor_explicit_kernel(const T* __rest
                                                                   int nx, int ny, PredK<T> k) {
     const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
     if (j >= ny) return;
-    const size_t base = (size_t)blockIdx.z * nx * ny, c = base + (size_t)i * ny + j;
-    const T uc = un[c], vc = vn[c];
-    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { ui[c] = uc; vi[c] = vc; return; }
-    const size_t xp = c + ny, xm = c - ny, yp = c + 1, ym = c - 1;
-    const T u1c = un1[c], v1c = vn1[c];
-    const T three_half = (T)1.5, half = (T)0.5, two = (T)2;
-    {
-        const T e = un[xp], w = un[xm], e1 = un1[xp], w1 = un1[xm];
-        const T n = un[yp], so = un[ym], n1 = un1[yp], so1 = un1[ym];
-        const T adv = uc * (e - w) / k.two_dx + vc * (CORRECT ? n - so : e - w) / k.two_dy;          // :73-74 (x-difference twice)
-        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (CORRECT ? n1 - so1 : e1 - w1) / k.two_dy;  // :75-76
-        const T lap = (e - two * uc + w) / k.dx2 + (n - two * uc + so) / k.dy2;
-        const T lap1 = (e1 - two * u1c + w1) / k.dx2 + (n1 - two * u1c + so1) / k.dy2;
-        ui[c] = uc - k.dt * (three_half * adv - half * adv1) + k.dt_nu * (three_half * lap - half * lap1);
-    }
-    {
-        const T e = vn[xp], w = vn[xm], e1 = vn1[xp], w1 = vn1[xm];
-        const T n = vn[yp], so = vn[ym], n1 = vn1[yp], so1 = vn1[ym];
-        const T adv = uc * (e - w) / k.two_dx + vc * (CORRECT ? n - so : e - w) / k.two_dy;          // :82-83
-        const T adv1 = u1c * (e1 - w1) / k.two_dx + v1c * (CORRECT ? n1 - so1 : e1 - w1) / k.two_dy;
-        const T lap = (e - two * vc + w) / k.dx2 + (n - two * vc + so) / k.dy2;
-        const T lap1 = (e1 - two * v1c + w1) / k.dx2 + (n1 - two * v1c + so1) / k.dy2;
-        vi[c] = vc - k.dt * (three_half * adv - half * adv1) + k.dt_nu * (three_half * lap - half * lap1);
-    }
+    const size_t base = (size_t)blockIdx.z * nx * ny;
+    predictor_explicit_point<T, CORRECT>(un + base, vn + base, un1 + base, vn1 + base, ui + base, vi + base, i, j, nx, ny, k);
 }
 
 template <typename T>
@@ -118,7 +60,7 @@ int predictor_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* 
                        double dt, double dx, double dy, double nu, hipStream_t s, bool corrected = false, bool column_slab = false) {
     if (!un || !vn || !un1 || !vn1 || !ui || !vi || !field_args_ok(batch, nx, ny))
         return fail(NNS_ERR_INVALID_ARG, "fd_predictor_explicit: bad args (batch=%d nx=%d ny=%d)", batch, nx, ny);
-    PredK<T> k{(T)dt, (T)(2 * dx), (T)(2 * dy), (T)(dx * dx), (T)(dy * dy), (T)(dt * nu)};
+    const PredK<T> k = make_pred<T>(dt, dx, dy, nu);
     if (corrected) hipLaunchKernelGGL((predictor_explicit_kernel<T, true>), grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, un1, vn1, ui, vi, nx, ny, k);
     else hipLaunchKernelGGL((predictor_explicit_kernel<T, false>), grid2d(batch, nx, ny), dim3(kTX), 0, s, un, vn, un1, vn1, ui, vi, nx, ny, k);
     return check_launch("fd_predictor_explicit");
@@ -363,15 +305,15 @@ __global__ __launch_bounds__(kTX) void pressure_rhs_kernel(const T* __restrict__
                                                             int nx, int ny, T cu, T cv) {
     const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
     if (j >= ny) return;
-    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
-    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { C[c] = (T)0; return; }
-    C[c] = cu * (ui[c] - ui[c - ny]) + cv * (vi[c] - vi[c - 1]);
+    const size_t base = (size_t)blockIdx.z * nx * ny;
+    C[base + (size_t)i * ny + j] = pressure_rhs_point<T>(ui + base, vi + base, i, j, nx, ny, cu, cv);
 }
 
 template <typename T>
 int pressure_rhs(const T* ui, const T* vi, T* C, int batch, int nx, int ny, double dt, double dx, double dy, double rho, hipStream_t s) {
     if (!ui || !vi || !C || !field_args_ok(batch, nx, ny)) return fail(NNS_ERR_INVALID_ARG, "fd_pressure_rhs: bad args");
-    const T cu = (T)(dx * rho * (dy * dy) / dt), cv = (T)(dy * rho * (dx * dx) / dt);        // :187-188
+    T cu, cv;
+    rhs_consts<T>(dt, dx, dy, rho, cu, cv);
     hipLaunchKernelGGL(pressure_rhs_kernel<T>, grid2d(batch, nx, ny), dim3(kTX), 0, s, ui, vi, C, nx, ny, cu, cv);
     return check_launch("fd_pressure_rhs");
 }
@@ -381,11 +323,8 @@ __global__ __launch_bounds__(kTX) void correction_kernel(const T* __restrict__ u
                                                           T* __restrict__ u, T* __restrict__ v, int nx, int ny, T cx, T cy) {
     const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y;
     if (j >= ny) return;
-    const size_t c = (size_t)blockIdx.z * nx * ny + (size_t)i * ny + j;
-    const T uc = ui[c], vc = vi[c];
-    if (i == 0 || i == nx - 1 || j == 0 || j == ny - 1) { u[c] = uc; v[c] = vc; return; }
-    u[c] = uc - cx * (p[c + ny] - p[c - ny]);
-    v[c] = vc - cy * (p[c + 1] - p[c - 1]);
+    const size_t base = (size_t)blockIdx.z * nx * ny;
+    correction_point<T>(ui + base, vi + base, p + base, ny, u + base, v + base, i, j, nx, ny, cx, cy);
 }
 
 template <typename T>

@@ -42,6 +42,7 @@ _DUAL = {
     'nns_fd_sor_redblack': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_sor_redblack_halfsweep': [_P] * 3 + [_I] * 4 + [_D] * 3 + [_P],
     'nns_fd_correction': [_P] * 5 + [_I] * 3 + [_D] * 3 + [_P],
+    'nns_fd_step_explicit': [_P] * 5 + [_BCP] * 3 + [_P] * 5 + [_I] * 3 + [_D] * 7 + [_I, _I, _P],
     'nns_fd_build_b': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_jacobi': [_P] * 3 + [_I] * 3 + [_D] * 2 + [_I, _BCP, _P],
     'nns_fd_direct_update': [_P] * 5 + [_I] * 3 + [_D] * 5 + [_P],
@@ -89,6 +90,7 @@ _SINGLE = {
     'nns_basis_loss_fwd_f32': [_P] * 4 + [_I] * 4 + [_P],
     'nns_basis_loss_bwd_f32': [_P] * 3 + [C.c_float] + [_P] * 2 + [_I] * 4 + [_P],
     'nns_basis_loss_fused_f32': [_P] * 6 + [_I] * 4 + [_P],
+    'nns_fd_step_explicit_fits': [_I, _I, _I],
     'nns_adam_step_f32': [_PP] * 4 + [C.POINTER(C.c_long), _I] + [_D] * 5 + [_L, _I, _P],
     'nns_pinn_workspace_bytes': [],
     'nns_pinn_assemble_f32': [_P] * 9 + [_I, _L, _P],

@@ -69,7 +69,30 @@ class NavierStokesSystem():
         self.last_sor_info = solve(p, C, self.dx, self.dy, self.beta, SOR_TOL, max(int(self.nit) - 1, 0))
         return p
 
-    def _step_dev(self, un, vn, un1, vn1, p):
+    def _fused_step_applies(self, p):
+        """The explicit method with the lexicographic solve on a grid whose p and right-hand side fit one workgroup's LDS (the reference's 51 x 51,
+        BASELINE config 1's 64 x 64): the whole step is ONE launch (nns_fd_step_explicit_*), bitwise the separate operators.  fused_step=False on the
+        instance keeps the separate launches (tests compare the two)."""
+        return (getattr(self, 'fused_step', True) and self.method == 'explicit' and self.pressure_solver == 'sor'
+                and None not in (self._u_bcl, self._v_bcl, self._p_bcl) and ops.fd_step_explicit_fits(p.shape[-2], p.shape[-1], p.dtype))
+
+    def _step_dev(self, un, vn, un1, vn1, p, out=None, p_copy=None):
+        """One step on device tensors; p is updated in place.  out = (u, v): fields to write the new velocities to (not inputs); p_copy: a field
+        that also receives the new p (a trajectory slot)."""
+        if self._fused_step_applies(p):
+            u, v, self.last_sor_info = ops.fd_step_explicit(un, vn, un1, vn1, p, self._u_bcl, self._v_bcl, self._p_bcl, self.dt, self.dx, self.dy, self.rho,
+                                                            self.nu, self.beta, SOR_TOL, max(int(self.nit) - 1, 0), corrected=self.advection == 'corrected',
+                                                            out=out, p_copy=p_copy)
+            return u, v, p
+        u, v, p = self._step_dev_separate(un, vn, un1, vn1, p)
+        if out is not None:
+            out[0].copy_(u), out[1].copy_(v)
+            u, v = out
+        if p_copy is not None:
+            p_copy.copy_(p)
+        return u, v, p
+
+    def _step_dev_separate(self, un, vn, un1, vn1, p):
         ui, vi = self._predict_dev(un, vn, un1, vn1)
         ops.bc_apply_(ui, self._u_bcl)
         ops.bc_apply_(vi, self._v_bcl)
@@ -151,10 +174,9 @@ class NavierStokesSystem():
                 us[n].copy_(u), vs[n].copy_(v), ps[n].copy_(p)
             return us, vs, ps
         for n in range(self.nt):
-            _u, _v, p = self._step_dev(u, v, u1, v1, p)
+            _u, _v, p = self._step_dev(u, v, u1, v1, p, out=(us[n], vs[n]), p_copy=ps[n])     # straight into the trajectory: the next step reads it there
             u1, v1 = u, v
             u, v = _u, _v
-            us[n].copy_(u), vs[n].copy_(v), ps[n].copy_(p)
         return us, vs, ps
 
     def simulate(self):

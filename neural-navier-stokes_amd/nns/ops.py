@@ -176,6 +176,27 @@ def fd_correction(ui, vi, p, dt, dx, dy):
     return u, v
 
 
+def fd_step_explicit_fits(nx, ny, dtype):
+    """Does the one-launch explicit step apply to this grid (p and its right-hand side in one workgroup's LDS)?"""
+    return bool(_lib.lib().nns_fd_step_explicit_fits(int(nx), int(ny), 8 if dtype == torch.float64 else 4))
+
+
+def fd_step_explicit(un, vn, un1, vn1, p, u_bcl, v_bcl, p_bcl, dt, dx, dy, rho, nu, beta, tol, max_sweeps, corrected=False, out=None, p_copy=None):
+    """chorin_fd's explicit step in ONE launch (nns_fd_step_explicit_*): predictor, boundary lists, pressure solve, correction.  p is updated in
+    place (and copied to p_copy when given); returns (u, v, info) with u, v = `out` (two fields that are not inputs) or new tensors."""
+    suf, (B, nx, ny) = _chk(un, vn, un1, vn1, p)
+    u, v = out if out is not None else (torch.empty_like(un), torch.empty_like(un))
+    _chk(un, u, v)
+    if p_copy is not None:
+        _chk(un, p_copy)
+    info = torch.empty(B, 2, dtype=p.dtype, device=p.device)
+    nbytes = _lib.lib().nns_fd_sor_workspace(B, nx, ny, p.element_size())
+    work = torch.empty(nbytes // p.element_size(), dtype=p.dtype, device=p.device)
+    _call('nns_fd_step_explicit', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(p), u_bcl, v_bcl, p_bcl, _p(u), _p(v), _p(p_copy) if p_copy is not None else None,
+          _p(info), _p(work), B, nx, ny, dt, dx, dy, rho, nu, beta, tol, int(max_sweeps), int(bool(corrected)), _stream())
+    return u, v, info
+
+
 def coarsen(u, v, p, agg_x, agg_y, jfill=None):
     """Block means of the [T, nx, ny] device sequences u, v, p over agg_x x agg_y cells (nns_coarsen_*).
     jfill: coarse columns filled per row (the rest are 0); default ny / agg_y."""

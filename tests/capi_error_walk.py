@@ -45,7 +45,7 @@ for base, args in _lib._DUAL.items():
     names[base + '_f32'] = args
     names[base + '_f64'] = args
 queries = ('nns_version', 'nns_last_error', 'nns_device_info', 'nns_ode_mlp_bwd_workspace', 'nns_fd_predictor_adi_workspace', 'nns_fd_sor_workspace',
-           'nns_fd_sor_redblack_workspace', 'nns_spec_resolve_precise', 'nns_pinn_workspace_bytes')
+           'nns_fd_sor_redblack_workspace', 'nns_spec_resolve_precise', 'nns_pinn_workspace_bytes', 'nns_fd_step_explicit_fits')
 for name, argtypes in sorted(names.items()):
     if name in queries:
         continue
@@ -113,6 +113,7 @@ expect('slab pack_halo g0 + Bc > B', L.nns_slab_pack_halo_f32(ptrs5, 3, P, P, P,
 expect('slab pack_halo one halo buffer', L.nns_slab_pack_halo_f64(ptrs5, 3, P, P, None, 4, 0, 2, 8, 64, 4, None), INVALID)
 expect('slab pack_halo ny / P not a vector multiple', L.nns_slab_pack_halo_f32(ptrs5, 3, P, None, None, 4, 0, 2, 8, 12, 4, None), UNSUPPORTED)
 assert L.nns_pinn_workspace_bytes() >= 4 * 1024 * 8
+assert L.nns_fd_step_explicit_fits(64, 64, 8) == 1 and L.nns_fd_step_explicit_fits(200, 200, 8) == 0 and L.nns_fd_step_explicit_fits(64, 64, 2) == 0
 expect('pinn assemble one prev field', L.nns_pinn_assemble_f32(P, P, P, P, P, P, P, None, P, 2, 64, None), INVALID)
 expect('pinn assemble misaligned workspace', L.nns_pinn_assemble_f32(P, P, P, P, P, P, None, None, P + 4, 2, 64, None), INVALID)
 expect('pinn loss n = 0', L.nns_pinn_loss_f32(P, P, P, 0, P, 0.0, 1.0, 1.0, P, None), INVALID)

@@ -555,3 +555,43 @@ def test_corrected_adi_vs_oracle(gpu_device, dtype):
         u, v, p = NavierStokesSystem(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, advection='corrected', **kw).simulate()
         ur, vr, pr = O.simulate(z.copy(), z.copy(), z.copy(), u_bc, v_bc, p_bc, nt, 50, 1e-3, 1, 0.05, 1.25, 'semi_implicit', advection='corrected')
         assert np.abs(u - ur).max() < 1e-9 and np.abs(p - pr).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,B,dtype,advection,nit', [(64, 1, np.float64, 'reference', 50), (51, 1, np.float64, 'reference', 50), (33, 3, np.float32, 'corrected', 20),
+                                                      (64, 2, np.float64, 'corrected', 9), (17, 1, np.float64, 'reference', 200), (96, 2, np.float32, 'reference', 30), (80, 1, np.float64, 'reference', 15)])
+def test_fused_explicit_step_is_bitwise_the_separate_operators(n, B, dtype, advection, nit, gpu_device):
+    """Round 4: chorin_fd's explicit step as ONE launch (nns_fd_step_explicit_*: predictor, boundary lists, right-hand side, lexicographic SOR,
+    pressure boundary list, correction by one workgroup per grid) against the seven separate launches -- the same per-point functions, so u, v, p,
+    the sweep counts and the last errors must agree BITWISE over a cavity run (early stops of the solve included once the flow has developed),
+    single grids and batches, both advection forms, float64 and float32; the C entry refuses aliased outputs and grids that do not fit LDS."""
+    from nns import ops, _lib
+    from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+    from nns.chorin_fd import NavierStokesSystem
+    dx = dy = 2. / (n - 1)
+    u_bc = [D(0., 'left', dx, dy), D(1., 'right', dx, dy), D(0., 'top', dx, dy), D(0., 'bottom', dx, dy)]
+    v_bc = [D(0., 'left', dx, dy), D(0., 'right', dx, dy), N(0.5, 'top', dx, dy), D(0., 'bottom', dx, dy)]
+    p_bc = [D(0., 'top', dx, dy), N(0., 'bottom', dx, dy), N(0.25, 'left', dx, dy), N(0., 'right', dx, dy)]
+    rng = np.random.default_rng(n + B)
+    shape = (n, n) if B == 1 else (B, n, n)
+    ic = [0.05 * rng.standard_normal(shape) for _ in range(3)]
+    runs = []
+    for fused in (True, False):
+        s = NavierStokesSystem(ic[0].copy(), ic[1].copy(), ic[2].copy(), u_bc, v_bc, p_bc, nt=12, nit=nit, nx=n, ny=n, dt=1e-3, rho=1.1, nu=0.02, beta=1.25,
+                               method='explicit', dtype=dtype, advection=advection)
+        s.fused_step = fused
+        assert s._fused_step_applies(s._d(ic[2])) == fused
+        us, vs, ps = s.simulate_device()
+        runs.append((us, vs, ps, s.last_sor_info.clone()))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+    assert float(runs[0][0].abs().max()) > 0.5                     # the lid moves the fluid
+    # the C entry's refusals
+    f = [torch.zeros(1, n, n, dtype=torch.float64 if dtype == np.float64 else torch.float32, device='cuda') for _ in range(6)]
+    bl = ops.make_bc_list(u_bc)
+    with pytest.raises(_lib.NnsError, match='must not be input'):
+        ops.fd_step_explicit(f[0], f[1], f[2], f[3], f[4], bl, bl, bl, 1e-3, dx, dy, 1.0, 0.02, 1.25, 1e-3, 5, out=(f[0], f[5]))
+    big = [torch.zeros(1, 200, 200, dtype=torch.float64, device='cuda') for _ in range(5)]
+    assert not ops.fd_step_explicit_fits(200, 200, torch.float64)
+    with pytest.raises(_lib.NnsError, match='does not fit'):
+        ops.fd_step_explicit(*big, bl, bl, bl, 1e-3, dx, dy, 1.0, 0.02, 1.25, 1e-3, 5)

@@ -8,6 +8,7 @@ TAG=$1; FLAGS=$2
 C=neural-navier-stokes_amd/csrc; O=ab_variants; mkdir -p $O/$TAG
 HIP="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fvisibility=hidden $FLAGS"
 EXACT="fd_kernels sor_kernels cheb_kernels coarsen_kernels spectral_dense"
+EXACT="$EXACT fd_step_kernels"
 PLAIN="residual_kernels spectral_kernels spectral_seg_kernels spectral_bwd_kernels neural_kernels pixel_mlp_kernels pixel_mlp_fwd4 spectral_ops slab_kernels pinn_kernels optim_kernels"
 want() { [ -z "$AB_ONLY" ] || [[ " $AB_ONLY " == *" $1 "* ]]; }
 for f in $EXACT; do if want $f; then $HIP -ffp-contract=off -c $C/$f.hip -o $O/$TAG/$f.o & else cp $C/$f.o $O/$TAG/$f.o; fi; done
