@@ -112,10 +112,17 @@ int nns_fd_pressure_rhs_f64(const double* ui, const double* vi, double* C, int b
  * info[2*b] = sweeps done, info[2*b+1] = last err (as the field type), per grid b.
  * work: nns_fd_sor_workspace() bytes. One workgroup per grid ("replicas only" across GPUs). */
 size_t nns_fd_sor_workspace(int batch, int nx, int ny, int elem_size);
+/* (The sweeps run speculatively in batches; a stop inside a batch costs a restore + replay.  nns_fd_sor_hint_* take `hint` [batch][2] -- the info of the
+ * PREVIOUS solve of the same grids in a time loop, device memory, may be the same buffer as info, NULL = none -- and size the first batch by its sweep
+ * count: a scheduling hint only, the results do not depend on it.) */
 int nns_fd_sor_f32(float* p, const float* C, float* info, void* work, int batch, int nx, int ny,
                    double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
 int nns_fd_sor_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny,
                    double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
+int nns_fd_sor_hint_f32(float* p, const float* C, float* info, const float* hint, void* work, int batch, int nx, int ny,
+                        double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
+int nns_fd_sor_hint_f64(double* p, const double* C, double* info, const double* hint, void* work, int batch, int nx, int ny,
+                        double dx, double dy, double beta, double tol, int max_sweeps, void* stream);
 
 /* ---- corrected / extended solver options (NOT reference behaviour) ----------------
  * Explicit predictor with the true y-advection  v d/dy  (the reference differences along x twice, :73-76,:82-85);
@@ -179,14 +186,14 @@ int nns_coarsen_f64(const double* u, const double* v, const double* p, double* c
  * sequence nns_fd_predictor_explicit(_corrected) / nns_bc_apply x 2 / nns_fd_pressure_rhs / nns_fd_sor / nns_bc_apply / nns_fd_correction (the same
  * per-point functions).  p is updated in place (as the reference mutates it) and also written to p_copy when that is not NULL (a trajectory slot);
  * u_out, v_out receive the new velocities (they hold the intermediate ones on the way: they must not alias an input field); info [batch][2] =
- * (sweeps, last err); work: nns_fd_sor_workspace(batch, nx, ny, elem) bytes.  Applies when p and its right-hand side fit one workgroup's LDS
+ * (sweeps, last err); hint: as nns_fd_sor_hint_* (the previous step's info or NULL); work: nns_fd_sor_workspace(batch, nx, ny, elem) bytes.  Applies when p and its right-hand side fit one workgroup's LDS
  * (nns_fd_step_explicit_fits: 64 x 64 float64, 96 x 96 float32 and below); NNS_ERR_UNSUPPORTED otherwise: use the separate calls. */
 int nns_fd_step_explicit_fits(int nx, int ny, int elem_size);
 int nns_fd_step_explicit_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* p, const nns_bc_list* u_bc, const nns_bc_list* v_bc,
-                             const nns_bc_list* p_bc, float* u_out, float* v_out, float* p_copy, float* info, void* work, int batch, int nx, int ny,
+                             const nns_bc_list* p_bc, float* u_out, float* v_out, float* p_copy, float* info, const float* hint, void* work, int batch, int nx, int ny,
                              double dt, double dx, double dy, double rho, double nu, double beta, double tol, int max_sweeps, int corrected, void* stream);
 int nns_fd_step_explicit_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* p, const nns_bc_list* u_bc, const nns_bc_list* v_bc,
-                             const nns_bc_list* p_bc, double* u_out, double* v_out, double* p_copy, double* info, void* work, int batch, int nx, int ny,
+                             const nns_bc_list* p_bc, double* u_out, double* v_out, double* p_copy, double* info, const double* hint, void* work, int batch, int nx, int ny,
                              double dt, double dx, double dy, double rho, double nu, double beta, double tol, int max_sweeps, int corrected, void* stream);
 
 /* _correction_step (:204-210): u = u* - dt/(2dx) d0x p, v = v* - dt/(2dy) d0y p; edges from u*. */

@@ -30,7 +30,7 @@ struct StepK { PredK<T> pred; T cu, cv, cx, cy; SorK<T> sor; };
 // live in the output fields.
 template <typename T, bool CORRECT, bool UV_LDS>
 __global__ __launch_bounds__(kSorThreads) void fd_step_explicit_kernel(const T* __restrict__ un, const T* __restrict__ vn, const T* __restrict__ un1,
-                                                                        const T* __restrict__ vn1, T* p, T* u_out, T* v_out, T* p_copy, T* __restrict__ info,
+                                                                        const T* __restrict__ vn1, T* p, T* u_out, T* v_out, T* p_copy, T* info, const T* hint,
                                                                         T* __restrict__ snap, int nx, int ny, int max_sweeps, StepK<T> k,
                                                                         BcListDev<T> ubc, BcListDev<T> vbc, BcListDev<T> pbc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kSorThreads) void fd_step_explicit_kernel(const T* 
 #endif
     int done;
     T err;
-    sor_solve<T, true>(pl, cl, snap + base, nx, ny, max_sweeps, k.sor, errs, s_stop_p, done, err);
+    const int expect = hint ? (int)hint[2 * blockIdx.x] : 0;          // (before info is written: the two may be one buffer)
+    sor_solve<T, true>(pl, cl, snap + base, nx, ny, max_sweeps, expect, k.sor, errs, s_stop_p, done, err);
 #if NNS_STEP_TIMING
     tq[4] = clock64();
 #endif
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kSorThreads) void fd_step_explicit_kernel(const T* 
 
 template <typename T>
 int step_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* p, const nns_bc_list* u_bc, const nns_bc_list* v_bc, const nns_bc_list* p_bc,
-                  T* u_out, T* v_out, T* p_copy, T* info, void* work, int batch, int nx, int ny, double dt, double dx, double dy, double rho, double nu,
+                  T* u_out, T* v_out, T* p_copy, T* info, const T* hint, void* work, int batch, int nx, int ny, double dt, double dx, double dy, double rho, double nu,
                   double beta, double tol, int max_sweeps, int corrected, hipStream_t s) {
     if (!un || !vn || !un1 || !vn1 || !p || !u_out || !v_out || !info || !work || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_step_explicit: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
@@ -119,7 +120,7 @@ int step_explicit(const T* un, const T* vn, const T* un1, const T* vn1, T* p, co
             if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_step_explicit: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr[slot] = true;
         }
-        hipLaunchKernelGGL(kern, dim3(batch), dim3(kSorThreads), uv ? lds4 : lds, s, un, vn, un1, vn1, p, u_out, v_out, p_copy, info, snap, nx, ny, max_sweeps, k, ub, vb, pb);
+        hipLaunchKernelGGL(kern, dim3(batch), dim3(kSorThreads), uv ? lds4 : lds, s, un, vn, un1, vn1, p, u_out, v_out, p_copy, info, hint, snap, nx, ny, max_sweeps, k, ub, vb, pb);
         return NNS_OK;
     };
     int rc;
@@ -136,15 +137,15 @@ NNS_API int nns_fd_step_explicit_fits(int nx, int ny, int elem_size) {
 }
 
 NNS_API int nns_fd_step_explicit_f32(const float* un, const float* vn, const float* un1, const float* vn1, float* p, const nns_bc_list* u_bc, const nns_bc_list* v_bc,
-                                     const nns_bc_list* p_bc, float* u_out, float* v_out, float* p_copy, float* info, void* work, int batch, int nx, int ny,
+                                     const nns_bc_list* p_bc, float* u_out, float* v_out, float* p_copy, float* info, const float* hint, void* work, int batch, int nx, int ny,
                                      double dt, double dx, double dy, double rho, double nu, double beta, double tol, int max_sweeps, int corrected, void* stream) {
-    return step_explicit<float>(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, u_out, v_out, p_copy, info, work, batch, nx, ny, dt, dx, dy, rho, nu, beta, tol, max_sweeps,
+    return step_explicit<float>(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, u_out, v_out, p_copy, info, hint, work, batch, nx, ny, dt, dx, dy, rho, nu, beta, tol, max_sweeps,
                                 corrected, (hipStream_t)stream);
 }
 NNS_API int nns_fd_step_explicit_f64(const double* un, const double* vn, const double* un1, const double* vn1, double* p, const nns_bc_list* u_bc,
-                                     const nns_bc_list* v_bc, const nns_bc_list* p_bc, double* u_out, double* v_out, double* p_copy, double* info, void* work, int batch,
+                                     const nns_bc_list* v_bc, const nns_bc_list* p_bc, double* u_out, double* v_out, double* p_copy, double* info, const double* hint, void* work, int batch,
                                      int nx, int ny, double dt, double dx, double dy, double rho, double nu, double beta, double tol, int max_sweeps, int corrected,
                                      void* stream) {
-    return step_explicit<double>(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, u_out, v_out, p_copy, info, work, batch, nx, ny, dt, dx, dy, rho, nu, beta, tol, max_sweeps,
+    return step_explicit<double>(un, vn, un1, vn1, p, u_bc, v_bc, p_bc, u_out, v_out, p_copy, info, hint, work, batch, nx, ny, dt, dx, dy, rho, nu, beta, tol, max_sweeps,
                                  corrected, (hipStream_t)stream);
 }

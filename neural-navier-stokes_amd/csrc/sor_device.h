@@ -179,13 +179,20 @@ __device__ __forceinline__ void sor_run_batch(T* pw, const T* cw, int nx, int ny
 // itself), sg = the grid's snapshot buffer (global, nx * ny), errs / s_stop_p = the LDS header.  Runs speculative batches of sweeps until the first
 // sweep whose maximum update is <= tol (kept exact: restore + replay) or max_sweeps; returns the sweeps done and the last error (:183-200).
 template <typename T, bool IN_LDS>
-__device__ __forceinline__ void sor_solve(T* pw, const T* cw, T* sg, int nx, int ny, int max_sweeps, const SorK<T>& k, T* errs, int* s_stop_p,
+__device__ __forceinline__ void sor_solve(T* pw, const T* cw, T* sg, int nx, int ny, int max_sweeps, int expect, const SorK<T>& k, T* errs, int* s_stop_p,
                                           int& done_out, T& err_out) {
     const int n = nx * ny, tid = threadIdx.x;
-    int done = 0;
+    int done = 0, nbatch = 0;
     T err = (T)1;                                                     // :183
     while (done < max_sweeps) {
-        const int nsw = min(sor_rows_path<IN_LDS>(nx) ? kSorBatch : kSorWaves, max_sweeps - done);
+        // Sweeps run speculatively in batches (a stop inside a batch costs a restore + replay), so the batch sizes follow what is known: `expect`
+        // (the sweep count of the previous solve of this grid, 0 = unknown) for the first one -- a time loop's counts change slowly, and a batch
+        // that ends exactly at the stop needs no replay --, one sweep per wave for the second, whatever is left (up to the cap) after that.
+        // The RESULT does not depend on the batch sizes.
+        int want = nbatch == 0 ? (expect >= 1 ? expect : kSorWaves) : nbatch == 1 ? kSorWaves : kSorBatch;
+        if (!sor_rows_path<IN_LDS>(nx)) want = kSorWaves;
+        const int nsw = min(min(want, sor_rows_path<IN_LDS>(nx) ? kSorBatch : kSorWaves), max_sweeps - done);
+        ++nbatch;
         for (int c = tid; c < n; c += kSorThreads) sg[c] = pw[c];      // snapshot for an exact early stop
         __syncthreads();
         sor_run_batch<T, IN_LDS>(pw, cw, nx, ny, nsw, k, errs);

@@ -26,7 +26,7 @@ namespace {
 
 template <typename T, bool IN_LDS>
 __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, const T* __restrict__ C, T* __restrict__ info,
-                                                           T* __restrict__ snap, int nx, int ny, int max_sweeps, SorK<T> k) {
+                                                           T* __restrict__ snap, const T* __restrict__ hint, int nx, int ny, int max_sweeps, SorK<T> k) {
     // all LDS in the dynamic region (16-byte aligned carve): [errs kSorBatch x 8 B][stop][pad][p][C]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* errs = reinterpret_cast<T*>(smem_raw);
@@ -46,13 +46,14 @@ __global__ __launch_bounds__(kSorThreads) void sor_kernel(T* __restrict__ p, con
     }
     int done;
     T err;
-    sor_solve<T, IN_LDS>(pw, cw, sg, nx, ny, max_sweeps, k, errs, s_stop_p, done, err);
+    const int expect = hint ? (int)hint[2 * blockIdx.x] : 0;       // read before info is written: hint may BE the info buffer of the previous solve
+    sor_solve<T, IN_LDS>(pw, cw, sg, nx, ny, max_sweeps, expect, k, errs, s_stop_p, done, err);
     if (IN_LDS) for (int c = tid; c < n; c += kSorThreads) pg[c] = pw[c];
     if (tid == 0) { info[2 * blockIdx.x] = (T)done; info[2 * blockIdx.x + 1] = err; }
 }
 
 template <typename T>
-int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double dx, double dy, double beta, double tol,
+int sor(T* p, const T* C, T* info, const T* hint, void* work, int batch, int nx, int ny, double dx, double dy, double beta, double tol,
         int max_sweeps, hipStream_t s) {
     if (!p || !C || !info || !work || !field_args_ok(batch, nx, ny) || max_sweeps < 0)
         return fail(NNS_ERR_INVALID_ARG, "fd_sor: bad args (batch=%d nx=%d ny=%d max_sweeps=%d)", batch, nx, ny, max_sweeps);
@@ -66,9 +67,9 @@ int sor(T* p, const T* C, T* info, void* work, int batch, int nx, int ny, double
             if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_sor: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr = true;
         }
-        hipLaunchKernelGGL((sor_kernel<T, true>), dim3(batch), dim3(kSorThreads), lds, s, p, C, info, snap, nx, ny, max_sweeps, k);
+        hipLaunchKernelGGL((sor_kernel<T, true>), dim3(batch), dim3(kSorThreads), lds, s, p, C, info, snap, hint, nx, ny, max_sweeps, k);
     } else {
-        hipLaunchKernelGGL((sor_kernel<T, false>), dim3(batch), dim3(kSorThreads), kSorHdr, s, p, C, info, snap, nx, ny, max_sweeps, k);
+        hipLaunchKernelGGL((sor_kernel<T, false>), dim3(batch), dim3(kSorThreads), kSorHdr, s, p, C, info, snap, hint, nx, ny, max_sweeps, k);
     }
     return check_launch("fd_sor");
 }
@@ -287,11 +288,19 @@ NNS_API size_t nns_fd_sor_workspace(int batch, int nx, int ny, int elem_size) {
 }
 NNS_API int nns_fd_sor_f32(float* p, const float* C, float* info, void* work, int batch, int nx, int ny, double dx, double dy,
                            double beta, double tol, int max_sweeps, void* stream) {
-    return sor<float>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+    return sor<float>(p, C, info, nullptr, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
 }
 NNS_API int nns_fd_sor_f64(double* p, const double* C, double* info, void* work, int batch, int nx, int ny, double dx, double dy,
                            double beta, double tol, int max_sweeps, void* stream) {
-    return sor<double>(p, C, info, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+    return sor<double>(p, C, info, nullptr, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_hint_f32(float* p, const float* C, float* info, const float* hint, void* work, int batch, int nx, int ny, double dx, double dy,
+                                double beta, double tol, int max_sweeps, void* stream) {
+    return sor<float>(p, C, info, hint, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
+}
+NNS_API int nns_fd_sor_hint_f64(double* p, const double* C, double* info, const double* hint, void* work, int batch, int nx, int ny, double dx, double dy,
+                                double beta, double tol, int max_sweeps, void* stream) {
+    return sor<double>(p, C, info, hint, work, batch, nx, ny, dx, dy, beta, tol, max_sweeps, reinterpret_cast<hipStream_t>(stream));
 }
 
 NNS_API size_t nns_fd_sor_redblack_workspace(int batch, int nx, int ny, int elem_size, int max_sweeps) {

@@ -39,10 +39,11 @@ _DUAL = {
     'nns_fd_predictor_adi_colslab': [_P] * 7 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_pressure_rhs': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_sor': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
+    'nns_fd_sor_hint': [_P] * 5 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_sor_redblack': [_P] * 4 + [_I] * 3 + [_D] * 4 + [_I, _P],
     'nns_fd_sor_redblack_halfsweep': [_P] * 3 + [_I] * 4 + [_D] * 3 + [_P],
     'nns_fd_correction': [_P] * 5 + [_I] * 3 + [_D] * 3 + [_P],
-    'nns_fd_step_explicit': [_P] * 5 + [_BCP] * 3 + [_P] * 5 + [_I] * 3 + [_D] * 7 + [_I, _I, _P],
+    'nns_fd_step_explicit': [_P] * 5 + [_BCP] * 3 + [_P] * 6 + [_I] * 3 + [_D] * 7 + [_I, _I, _P],
     'nns_fd_build_b': [_P] * 3 + [_I] * 3 + [_D] * 4 + [_P],
     'nns_fd_jacobi': [_P] * 3 + [_I] * 3 + [_D] * 2 + [_I, _BCP, _P],
     'nns_fd_direct_update': [_P] * 5 + [_I] * 3 + [_D] * 5 + [_P],

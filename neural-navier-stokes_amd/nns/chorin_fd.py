@@ -66,8 +66,15 @@ class NavierStokesSystem():
     def _pressure_dev_(self, ui, vi, p):
         C = ops.fd_pressure_rhs(ui, vi, self.dt, self.dx, self.dy, self.rho)
         solve = ops.fd_sor_redblack_ if self.pressure_solver == 'redblack' else ops.fd_sor_
-        self.last_sor_info = solve(p, C, self.dx, self.dy, self.beta, SOR_TOL, max(int(self.nit) - 1, 0))
+        kw = {} if self.pressure_solver == 'redblack' else dict(hint=self._hint_for(p))       # the previous solve's sweep count sizes the first batch
+        self.last_sor_info = solve(p, C, self.dx, self.dy, self.beta, SOR_TOL, max(int(self.nit) - 1, 0), **kw)
         return p
+
+    def _hint_for(self, p):
+        """The info of the previous pressure solve when it belongs to grids of this shape (a time loop): a scheduling hint for the next solve."""
+        h = self.last_sor_info
+        B = 1 if p.dim() == 2 else p.shape[0]
+        return h if (h is not None and h.dtype == p.dtype and h.device == p.device and tuple(h.shape) == (B, 2)) else None
 
     def _fused_step_applies(self, p):
         """The explicit method with the lexicographic solve on a grid whose p and right-hand side fit one workgroup's LDS (the reference's 51 x 51,
@@ -82,7 +89,7 @@ class NavierStokesSystem():
         if self._fused_step_applies(p):
             u, v, self.last_sor_info = ops.fd_step_explicit(un, vn, un1, vn1, p, self._u_bcl, self._v_bcl, self._p_bcl, self.dt, self.dx, self.dy, self.rho,
                                                             self.nu, self.beta, SOR_TOL, max(int(self.nit) - 1, 0), corrected=self.advection == 'corrected',
-                                                            out=out, p_copy=p_copy)
+                                                            out=out, p_copy=p_copy, hint=self._hint_for(p))
             return u, v, p
         u, v, p = self._step_dev_separate(un, vn, un1, vn1, p)
         if out is not None:

@@ -127,13 +127,22 @@ def fd_pressure_rhs(ui, vi, dt, dx, dy, rho):
     return C
 
 
-def fd_sor_(p, C, dx, dy, beta, tol, max_sweeps):
-    """In place on p.  Returns the device info tensor [batch, 2] = (sweeps done, last err)."""
+def _sor_hint(hint, B, p):
+    if hint is None:
+        return None
+    if not (isinstance(hint, torch.Tensor) and hint.is_cuda and hint.dtype == p.dtype and hint.is_contiguous() and tuple(hint.shape) == (B, 2)):
+        raise ValueError("SOR hint: the info tensor [batch, 2] of a previous solve of the same grids (same dtype and device) expected")
+    return _p(hint)
+
+
+def fd_sor_(p, C, dx, dy, beta, tol, max_sweeps, hint=None):
+    """In place on p.  Returns the device info tensor [batch, 2] = (sweeps done, last err).  hint: the info of the previous solve of the same
+    grids in a time loop (sizes the first speculative batch of sweeps; the result does not depend on it)."""
     suf, (B, nx, ny) = _chk(p, C)
     info = torch.empty(B, 2, dtype=p.dtype, device=p.device)
     nbytes = _lib.lib().nns_fd_sor_workspace(B, nx, ny, p.element_size())
     work = torch.empty(nbytes // p.element_size(), dtype=p.dtype, device=p.device)
-    _call('nns_fd_sor', suf, _p(p), _p(C), _p(info), _p(work), B, nx, ny, dx, dy, beta, tol, int(max_sweeps), _stream())
+    _call('nns_fd_sor_hint', suf, _p(p), _p(C), _p(info), _sor_hint(hint, B, p), _p(work), B, nx, ny, dx, dy, beta, tol, int(max_sweeps), _stream())
     return info
 
 
@@ -181,7 +190,7 @@ def fd_step_explicit_fits(nx, ny, dtype):
     return bool(_lib.lib().nns_fd_step_explicit_fits(int(nx), int(ny), 8 if dtype == torch.float64 else 4))
 
 
-def fd_step_explicit(un, vn, un1, vn1, p, u_bcl, v_bcl, p_bcl, dt, dx, dy, rho, nu, beta, tol, max_sweeps, corrected=False, out=None, p_copy=None):
+def fd_step_explicit(un, vn, un1, vn1, p, u_bcl, v_bcl, p_bcl, dt, dx, dy, rho, nu, beta, tol, max_sweeps, corrected=False, out=None, p_copy=None, hint=None):
     """chorin_fd's explicit step in ONE launch (nns_fd_step_explicit_*): predictor, boundary lists, pressure solve, correction.  p is updated in
     place (and copied to p_copy when given); returns (u, v, info) with u, v = `out` (two fields that are not inputs) or new tensors."""
     suf, (B, nx, ny) = _chk(un, vn, un1, vn1, p)
@@ -193,7 +202,7 @@ def fd_step_explicit(un, vn, un1, vn1, p, u_bcl, v_bcl, p_bcl, dt, dx, dy, rho, 
     nbytes = _lib.lib().nns_fd_sor_workspace(B, nx, ny, p.element_size())
     work = torch.empty(nbytes // p.element_size(), dtype=p.dtype, device=p.device)
     _call('nns_fd_step_explicit', suf, _p(un), _p(vn), _p(un1), _p(vn1), _p(p), u_bcl, v_bcl, p_bcl, _p(u), _p(v), _p(p_copy) if p_copy is not None else None,
-          _p(info), _p(work), B, nx, ny, dt, dx, dy, rho, nu, beta, tol, int(max_sweeps), int(bool(corrected)), _stream())
+          _p(info), _sor_hint(hint, B, p), _p(work), B, nx, ny, dt, dx, dy, rho, nu, beta, tol, int(max_sweeps), int(bool(corrected)), _stream())
     return u, v, info
 
 

@@ -595,3 +595,30 @@ def test_fused_explicit_step_is_bitwise_the_separate_operators(n, B, dtype, adve
     assert not ops.fd_step_explicit_fits(200, 200, torch.float64)
     with pytest.raises(_lib.NnsError, match='does not fit'):
         ops.fd_step_explicit(*big, bl, bl, bl, 1e-3, dx, dy, 1.0, 0.02, 1.25, 1e-3, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,dtype', [(64, torch.float64), (51, torch.float32), (80, torch.float64)])
+def test_sor_result_does_not_depend_on_the_sweep_count_hint(n, dtype, gpu_device):
+    """nns_fd_sor_hint_*: the previous solve's sweep count only sizes the first speculative batch of sweeps.  Whatever it says (right, too small,
+    too large, absurd), p, the sweep count and the last error are BITWISE those of the un-hinted solve -- early stops inside a batch included."""
+    from nns import ops
+    rng = np.random.default_rng(n)
+    for nit, tol in ((49, 1e-3), (49, 0.3), (120, 0.05), (3, 1e-9)):
+        p0 = torch.as_tensor(rng.standard_normal((2, n, n)), dtype=dtype, device='cuda')
+        C = torch.as_tensor(rng.standard_normal((2, n, n)) * 5, dtype=dtype, device='cuda')
+        ref = p0.clone()
+        info_ref = ops.fd_sor_(ref, C, 0.03, 0.04, 1.25, tol, nit)
+        for h in (1, 2, int(info_ref[0, 0].item()), int(info_ref[0, 0].item()) + 1, 49, 1000, 0, -7):
+            hint = torch.tensor([[h, 0.0], [max(h - 1, 0), 0.0]], dtype=dtype, device='cuda')
+            p = p0.clone()
+            info = ops.fd_sor_(p, C, 0.03, 0.04, 1.25, tol, nit, hint=hint)
+            assert torch.equal(p, ref) and torch.equal(info, info_ref), (nit, tol, h)
+        p = p0.clone()                                   # the hint may be the info buffer itself (read before it is written)
+        info = info_ref.clone()
+        from nns import _lib
+        nbytes = _lib.lib().nns_fd_sor_workspace(2, n, n, p.element_size())
+        work = torch.empty(nbytes // p.element_size(), dtype=dtype, device='cuda')
+        fn = getattr(_lib.lib(), 'nns_fd_sor_hint_f64' if dtype == torch.float64 else 'nns_fd_sor_hint_f32')
+        assert fn(p.data_ptr(), C.data_ptr(), info.data_ptr(), info.data_ptr(), work.data_ptr(), 2, n, n, 0.03, 0.04, 1.25, tol, nit, torch.cuda.current_stream().cuda_stream) == 0
+        assert torch.equal(p, ref) and torch.equal(info, info_ref)
