@@ -9,6 +9,7 @@
 // at each kernel (T = sizeof element).
 #include "nns_common.h"
 #include "fd_device.h"
+#include <cstdlib>
 
 using namespace nns;
 using namespace nns::fd;
@@ -168,6 +169,223 @@ __global__ __launch_bounds__(64) void predictor_adi_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// The same predictor for grids whose two working fields fit one workgroup's LDS (round 4: the reference's 51 x 51, BASELINE config 1's 64 x 64).
+// The kernel above is two lone waves walking 62 rows with a dozen global loads and a division chain per row in front of every recurrence step:
+// 120 us of the semi-implicit step's 0.32 ms.  Here ONE workgroup of 512 threads owns a grid: every right-hand side is computed by all threads at
+// once into LDS, the constant-coefficient factorisation (l[i] = lo / cp[i-1], cp[i], RN(1 / cp[i])) is tabulated ONCE per solve by one lane while
+// the others do that, and a recurrence step is then  y = rhs - l[i] y_prev  /  x = (y - up x_next) / cp[i]  on LDS operands.  Same expressions
+// on the same operands in the same order as the kernel above -- the division through div_exact, bitwise the IEEE quotient -- so the two kernels
+// agree BITWISE (test).
+// ------------------------------------------------------------------------------------------
+constexpr int kAdiLdsThreads = 512;
+#ifndef NNS_ADI_TIMING
+#define NNS_ADI_TIMING 0            // 1: predictor_adi_lds_kernel prints the cycles of its phases (workgroup 0, threads 0 and 448)
+#endif
+
+// x / den from rcp = RN(1 / den) (Markstein; see div_den in sor_device.h and tools/fastdiv_check.hip); rcp = 0 or an operand out of the safe
+// range: the plain division
+template <typename T>
+__device__ __forceinline__ T div_exact(T x, T den, T rcp) {
+    constexpr T lo = sizeof(T) == 8 ? (T)1e-250 : (T)1e-25, hi = sizeof(T) == 8 ? (T)1e250 : (T)1e25;
+    const T ax = fabs(x);
+    const T q = x * rcp;
+    T res = ax == (T)0 ? x : fma(fma(-q, den, x), rcp, q);                  // +-0 / den = +-0 (rcp != 0 only for den > 0)
+    if (!(rcp != (T)0 && ((ax >= lo && ax <= hi) || ax == (T)0))) res = x / den;
+    return res;
+}
+
+template <typename T>
+__device__ __forceinline__ void adi_tables(T diag, T lo, T up, int nx, T* l, T* cp, T* rc) {
+    constexpr T dlo = sizeof(T) == 8 ? (T)1e-50 : (T)1e-10, dhi = sizeof(T) == 8 ? (T)1e50 : (T)1e10;
+    // ONE division per row: RN(1 / cp[i-1]) is needed for the back substitution anyway, and lo / cp[i-1] follows from it exactly (div_exact)
+    // The recurrence c <- diag - (lo / c) up is a contraction (the matrix is diagonally dominant): in floating point it reaches a FIXED POINT after a
+    // handful of rows (4 at the reference's cavity parameters), after which every row repeats the same three numbers bit for bit -- the chain of
+    // divisions is cut there (it was 15 of this kernel's 48 us: a lone lane pays ~30 cycles per dependent float64 operation).
+    T c = diag, r = (c >= dlo && c <= dhi) ? (T)1 / c : (T)0, li = 0;
+    bool fixed = false;
+    for (int i = 1; i <= nx - 2; ++i) {
+        if (i > 1 && !fixed) {
+            const T ln = div_exact<T>(lo, c, r);
+            const T cn = diag - ln * up;
+            fixed = i > 2 && ln == li && cn == c;
+            if (!fixed) r = (cn >= dlo && cn <= dhi) ? (T)1 / cn : (T)0;
+            li = ln; c = cn;
+        }
+        l[i] = li; cp[i] = c; rc[i] = r;
+    }
+}
+
+// one column's forward elimination and back substitution in place on F[i * ny + j], i = 1 .. nx - 2: the streaming kernel's operations in its
+// order (bitwise the same numbers).  Eight rows' operands are requested before their eight dependent steps.  (Measured and dropped: the back
+// substitution re-associated as x = y / cp - (up / cp) x_next, two dependent operations per row instead of six -- 27.9 k cycles per solve against
+// 24.6 k: the lone wave that owns 62 columns is bound by the ~30 instructions of a row step, not by the chain, and the last bits then differ from
+// the streaming kernel that larger grids and other slab shapes take.)
+template <typename T>
+__device__ __forceinline__ void adi_column(T* F, int j, int nx, int ny, T up, const T* l, const T* cp, const T* rc) {
+    constexpr int U = 8;
+    T yprev = 0;
+    for (int i0 = 1; i0 <= nx - 2; i0 += U) {
+        T r[U], li[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = min(i0 + u, nx - 2); r[u] = F[i * ny + j]; li[u] = l[i]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            if (i <= nx - 2) {
+                const T y = i > 1 ? r[u] - li[u] * yprev : r[u];
+                F[i * ny + j] = y;
+                yprev = y;
+            }
+        }
+    }
+    T xnext = 0;
+    for (int i0 = nx - 2; i0 >= 1; i0 -= U) {
+        T r[U], ci[U], ri[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = max(i0 - u, 1); r[u] = F[i * ny + j]; ci[u] = cp[i]; ri[u] = rc[i]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 - u;
+            if (i >= 1) {
+                const T x = i == nx - 2 ? div_exact<T>(r[u], ci[u], ri[u]) : div_exact<T>(r[u] - up * xnext, ci[u], ri[u]);
+                F[i * ny + j] = x;
+                xnext = x;
+            }
+        }
+    }
+}
+
+// right-hand side of the first solve at interior point c of field fl (0: u, 1: v)   (:126-134)
+template <typename T>
+__device__ __forceinline__ T adi_rhs1_point(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ a1, const T* __restrict__ b1, int fl, int c,
+                                            int ny, const AdiK<T>& k) {
+    const T two = (T)2, three = (T)3;
+    const T* f = fl ? b : a;
+    const T* f1 = fl ? b1 : a1;
+    const T fc = f[c], fe = f[c + ny], fw = f[c - ny], fn = f[c + 1], fs = f[c - 1];
+    const T H = a[c] * (fe - fw) / k.two_dx + b[c] * (fn - fs) / k.two_dy;
+    const T H1 = a1[c] * (f1[c + ny] - f1[c - ny]) / k.two_dx + b1[c] * (f1[c + 1] - f1[c - 1]) / k.two_dy;
+    const T C1 = k.half_dt * (three * H - H1);
+    const T C2 = k.dt_nu * ((fe - two * fc + fw) / k.dx2 + (fn - two * fc + fs) / k.dy2);
+    return k.cx * (C1 + C2);
+}
+
+// The right-hand sides of the first solve by the WHOLE chip into `work` ([batch][2][nx][ny], interior points): eight float64 divisions per point
+// are 27 us for one workgroup and a launch latency for 256 CUs.
+template <typename T>
+__global__ __launch_bounds__(kTX) void adi_rhs1_kernel(const T* __restrict__ un, const T* __restrict__ vn, const T* __restrict__ un1, const T* __restrict__ vn1,
+                                                        T* __restrict__ work, int nx, int ny, AdiK<T> k) {
+    const int j = blockIdx.x * kTX + threadIdx.x, i = blockIdx.y, fl = blockIdx.z & 1;
+    if (j < 1 || j > ny - 2 || i < 1 || i > nx - 2) return;
+    const size_t base = (size_t)(blockIdx.z >> 1) * nx * ny;
+    work[(size_t)blockIdx.z * nx * ny + (size_t)i * ny + j] = adi_rhs1_point<T>(un + base, vn + base, un1 + base, vn1 + base, fl, i * ny + j, ny, k);
+}
+
+// RHS_READY: the first right-hand sides are in `work` (adi_rhs1_kernel); otherwise this workgroup computes them.
+template <typename T, bool FIRST_ONLY, bool RHS_READY>
+__global__ __launch_bounds__(kAdiLdsThreads) void predictor_adi_lds_kernel(const T* __restrict__ un, const T* __restrict__ vn,
+                                                                            const T* __restrict__ un1, const T* __restrict__ vn1,
+                                                                            T* __restrict__ ui, T* __restrict__ vi, T* __restrict__ work,
+                                                                            int nx, int ny, AdiK<T> k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = nx * ny, tid = threadIdx.x;
+    T* F = reinterpret_cast<T*>(smem_raw);          // [2][n]: the working fields of u and v
+    T* tab = F + 2 * n;                             // l, cp, rc of the two solves: 6 x [nx]
+    const size_t base = (size_t)blockIdx.x * n;
+    const T* a = un + base;  const T* b = vn + base;
+    const T* a1 = un1 + base; const T* b1 = vn1 + base;
+    const T two = (T)2;
+    const T lo = -k.dt, up = -k.dt;
+    constexpr int UG = 4;                           // points per thread and round of the global-memory phases: their loads are in flight together
+                                                    // (one point per round left every round waiting for its own loads: 16 x ~1000 cycles per phase)
+    auto inner = [&](int c) { const int i = c / ny, j = c - i * ny; return i >= 1 && i <= nx - 2 && j >= 1 && j <= ny - 2; };
+#if NNS_ADI_TIMING
+    long tq[8]; tq[0] = clock64();
+#endif
+    // the factorisations, one lane each, while everyone else starts on the right-hand sides
+    if (tid == 0) adi_tables<T>(k.a_diag, lo, up, nx, tab, tab + nx, tab + 2 * nx);
+    if (tid == kWave && !FIRST_ONLY) adi_tables<T>(k.b_diag, lo, up, nx, tab + 3 * nx, tab + 4 * nx, tab + 5 * nx);
+#if NNS_ADI_TIMING
+    tq[1] = clock64();
+#endif
+    // ---- first solve: A ut = (2/nu dx^2) (dt/2 (3H - H1) + dt nu lap f)        (:126-137)
+    for (int e0 = tid; e0 < 2 * n; e0 += UG * kAdiLdsThreads) {
+        T v[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = min(e0 + u * kAdiLdsThreads, 2 * n - 1), fl = e >= n, c = e - fl * n;
+            v[u] = RHS_READY ? work[(size_t)blockIdx.x * 2 * n + e] : (inner(c) ? adi_rhs1_point<T>(a, b, a1, b1, fl, c, ny, k) : (T)0);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) { const int e = e0 + u * kAdiLdsThreads; if (e < 2 * n) F[e] = v[u]; }
+    }
+    __syncthreads();
+#if NNS_ADI_TIMING
+    tq[2] = clock64();
+#endif
+    for (int q = tid; q < 2 * (ny - 2); q += kAdiLdsThreads) {
+        const int fl = q >= ny - 2, j = 1 + q - fl * (ny - 2);
+        adi_column<T>(F + fl * n, j, nx, ny, up, tab, tab + nx, tab + 2 * nx);
+    }
+    __syncthreads();
+#if NNS_ADI_TIMING
+    tq[3] = clock64();
+#endif
+    if (FIRST_ONLY) {                                                  // ut / vt to `work`: the corrected variant's second solve runs along axis 1
+        T* ft = work + (size_t)blockIdx.x * 2 * n;
+        for (int e = tid; e < 2 * n; e += kAdiLdsThreads) {
+            const int fl = e >= n, c = e - fl * n;
+            if (inner(c)) ft[e] = F[e];
+        }
+        return;
+    }
+    // ---- second solve: B ui = (2/nu dy^2)(ft + f) - dt d_yy f, again along axis 0   (:157-165)
+    for (int e0 = tid; e0 < 2 * n; e0 += UG * kAdiLdsThreads) {
+        T fc[UG], fp[UG], fm[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = min(e0 + u * kAdiLdsThreads, 2 * n - 1), fl = e >= n, c = e - fl * n;
+            const T* f = fl ? b : a;
+            const int cc = min(max(c, 1), n - 2);                       // (edge points are not used: any in-range address)
+            fc[u] = f[cc]; fp[u] = f[cc + 1]; fm[u] = f[cc - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = e0 + u * kAdiLdsThreads;
+            if (e < 2 * n && inner(e - (e >= n) * n)) F[e] = k.cy * (F[e] + fc[u]) - k.dt * (fp[u] - two * fc[u] + fm[u]);
+        }
+    }
+    __syncthreads();
+#if NNS_ADI_TIMING
+    tq[4] = clock64();
+#endif
+    for (int q = tid; q < 2 * (ny - 2); q += kAdiLdsThreads) {
+        const int fl = q >= ny - 2, j = 1 + q - fl * (ny - 2);
+        adi_column<T>(F + fl * n, j, nx, ny, up, tab + 3 * nx, tab + 4 * nx, tab + 5 * nx);
+    }
+    __syncthreads();
+#if NNS_ADI_TIMING
+    tq[5] = clock64();
+#endif
+    for (int e0 = tid; e0 < 2 * n; e0 += UG * kAdiLdsThreads) {
+        T fv[UG];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) { const int e = min(e0 + u * kAdiLdsThreads, 2 * n - 1), fl = e >= n; fv[u] = (fl ? b : a)[e - fl * n]; }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = e0 + u * kAdiLdsThreads;
+            if (e < 2 * n) { const int fl = e >= n, c = e - fl * n; ((fl ? vi : ui) + base)[c] = inner(c) ? F[e] : fv[u]; }     // ui = u.copy() on the edges
+        }
+    }
+#if NNS_ADI_TIMING
+    __syncthreads(); tq[6] = clock64();
+    if ((tid == 0 || tid == 448) && blockIdx.x == 0) printf("adi lds, thread %d (cycles): tables %ld, rhs1 / load %ld, solve 1 %ld, rhs2 %ld, solve 2 %ld, write %ld\n", tid, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5]);
+#endif
+}
+
+inline size_t adi_lds_bytes(int nx, int ny, size_t elem) { return (2 * (size_t)nx * ny + 6 * (size_t)nx) * elem; }
+
+// ------------------------------------------------------------------------------------------
 // Corrected option ("true y-direction ADI"; oracle: semi_implicit_predictor_corrected):
 // the second solve  B ui = (2/nu dy^2)(ut + u) - dt d_yy u  along axis 1 (rows), as an ADI scheme means it.
 // One thread per row would stride global memory by ny; instead a workgroup owns 64 rows and walks the columns in
@@ -276,14 +494,38 @@ int predictor_adi(const T* un, const T* vn, const T* un1, const T* vn1, T* ui, T
     const int tpb = 64;
     const size_t shmem = 2 * (size_t)nx * sizeof(T);
     if (shmem > 64 * 1024) return fail(NNS_ERR_UNSUPPORTED, "fd_predictor_adi: nx=%d too large for the LDS diagonal cache", nx);
-    if (!corrected) {
-        hipLaunchKernelGGL((predictor_adi_kernel<T, false>), dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
+    static const bool lds_path = [] { const char* e = getenv("NNS_ADI_LDS"); return !e || atoi(e) != 0; }();     // NNS_ADI_LDS=0: the streaming kernel always (A/B)
+    const size_t lds_all = adi_lds_bytes(nx, ny, sizeof(T));
+    const bool small = lds_path && lds_all <= 150 * 1024;
+    if (small) {
+        // right-hand sides chip-wide, then one workgroup per grid for the two solves (a grid of one row of workgroups would spend 27 us on them)
+        auto solve = [&](auto kern, int slot) -> int {
+            static bool attr2[2] = {false, false};
+            if (!attr2[slot]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                if (e != hipSuccess) return fail(NNS_ERR_LAUNCH, "fd_predictor_adi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr2[slot] = true;
+            }
+            hipLaunchKernelGGL(adi_rhs1_kernel<T>, dim3((ny + kTX - 1) / kTX, nx, 2 * batch), dim3(kTX), 0, s, un, vn, un1, vn1, work, nx, ny, k);
+            hipLaunchKernelGGL(kern, dim3(batch), dim3(kAdiLdsThreads), lds_all, s, un, vn, un1, vn1, ui, vi, work, nx, ny, k);
+            return NNS_OK;
+        };
+        if (!corrected) {
+            if (int rc = solve(predictor_adi_lds_kernel<T, false, true>, 0)) return rc;
+            return check_launch("fd_predictor_adi");
+        }
+        if (int rc = solve(predictor_adi_lds_kernel<T, true, true>, 1)) return rc;
+        if (int rc = check_launch("fd_predictor_adi (x solve)")) return rc;
+    } else {
+        if (!corrected) {
+            hipLaunchKernelGGL((predictor_adi_kernel<T, false>), dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
+                               un, vn, un1, vn1, ui, vi, work, nx, ny, k);
+            return check_launch("fd_predictor_adi");
+        }
+        hipLaunchKernelGGL((predictor_adi_kernel<T, true>), dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
                            un, vn, un1, vn1, ui, vi, work, nx, ny, k);
-        return check_launch("fd_predictor_adi");
+        if (int rc = check_launch("fd_predictor_adi (x solve)")) return rc;
     }
-    hipLaunchKernelGGL((predictor_adi_kernel<T, true>), dim3((ny + tpb - 1) / tpb, 2, batch), dim3(tpb), shmem, s,
-                       un, vn, un1, vn1, ui, vi, work, nx, ny, k);
-    if (int rc = check_launch("fd_predictor_adi (x solve)")) return rc;
     const size_t shy = ((size_t)ny + 2 * 64 * 65) * sizeof(T);
     if (shy > 150 * 1024) return fail(NNS_ERR_UNSUPPORTED, "fd_predictor_adi_corrected: ny=%d too large for the LDS diagonal cache", ny);
     static bool attr = false;

@@ -622,3 +622,39 @@ def test_sor_result_does_not_depend_on_the_sweep_count_hint(n, dtype, gpu_device
         fn = getattr(_lib.lib(), 'nns_fd_sor_hint_f64' if dtype == torch.float64 else 'nns_fd_sor_hint_f32')
         assert fn(p.data_ptr(), C.data_ptr(), info.data_ptr(), info.data_ptr(), work.data_ptr(), 2, n, n, 0.03, 0.04, 1.25, tol, nit, torch.cuda.current_stream().cuda_stream) == 0
         assert torch.equal(p, ref) and torch.equal(info, info_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nx,ny,B,dtype,corrected', [(64, 64, 1, torch.float64, False), (51, 51, 3, torch.float64, False), (33, 33, 2, torch.float32, False),
+                                                      (64, 64, 2, torch.float64, True), (40, 56, 1, torch.float32, True), (96, 96, 1, torch.float64, False)])
+def test_adi_predictor_lds_kernel_is_bitwise_the_streaming_kernel(nx, ny, B, dtype, corrected, gpu_device, monkeypatch):
+    """Round 4: the semi-implicit predictor of grids that fit one workgroup's LDS (right-hand sides chip-wide, the factorisation tabulated once and
+    cut at its floating-point fixed point, recurrences on LDS operands, divisions as Markstein's exact form) against the streaming kernel it
+    replaces there: the same expressions in the same order, so ui, vi agree BITWISE -- both advection forms, batches, float32 / float64, fields at
+    rest (zeros stay zeros)."""
+    import subprocess, sys, os, tempfile
+    from conftest import PKG, ROOT
+    code = '''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nns import ops
+rng = np.random.default_rng(3)
+dt_ = torch.float64 if %r == 'float64' else torch.float32
+f = [torch.as_tensor(rng.standard_normal((%d, %d, %d)) * s, dtype=dt_, device='cuda') for s in (1.0, 1.0, 0.9, 0.9)]
+outs = []
+for fields in (f, [torch.zeros_like(t) for t in f]):
+    ui, vi = ops.fd_predictor_adi(*fields, 1e-3, 0.03, 0.04 if %r else 0.03, 0.02, corrected=%r)
+    outs += [ui.cpu().numpy(), vi.cpu().numpy()]
+np.savez(sys.argv[1], *outs)
+''' % (PKG, str(dtype)[6:], B, nx, ny, corrected, corrected)
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for flag in ('1', '0'):
+            out = os.path.join(d, 'o%s.npz' % flag)
+            r = subprocess.run([sys.executable, '-c', code, out], env=dict(os.environ, NNS_ADI_LDS=flag), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            z = np.load(out)
+            res.append([z[k] for k in z.files])
+    for a, b in zip(*res):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert np.abs(res[0][0]).max() > 0.1 and not res[0][2].any() and not res[0][3].any()

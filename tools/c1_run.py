@@ -13,7 +13,7 @@ u_bc = [D(0, 'left', dx, dy), D(1, 'right', dx, dy), D(0, 'top', dx, dy), D(0, '
 v_bc = [D(0, 'left', dx, dy), D(0, 'right', dx, dy), D(0, 'top', dx, dy), D(0, 'bottom', dx, dy)]
 p_bc = [D(0, 'top', dx, dy), N(0, 'bottom', dx, dy), N(0, 'left', dx, dy), N(0, 'right', dx, dy)]
 z = np.zeros((n, n))
-s = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=200, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02, beta=1.25, method='explicit')
+s = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=200, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02, beta=1.25, method=os.environ.get("NNS_C1_METHOD", "explicit"))
 s.fused_step = os.environ.get('NNS_C1_FUSED', '1') != '0'
 s.simulate_device(use_graph=False)
 torch.cuda.synchronize(); t0 = time.perf_counter()
