@@ -72,7 +72,7 @@ def to_seg(parts, P):
 for it in range(NCASE):
     ny = int(rng.choice([64, 128, 256, 512, 1024]))
     P = int(rng.choice([p for p in (1, 2, 4, 8, 16) if ny // p >= max(16, ny // 16)]))
-    nloc = int(rng.integers(1, 40))
+    nloc = int(rng.integers(3, 40))                                  # (a row slab needs three local rows: the C ABI refuses fewer)
     B = int(rng.integers(1, max(2, min(600, int(2e7 // (nloc * ny))))))
     precise = int(rng.choice([0, 2]))
     g = gen(100 + it)
