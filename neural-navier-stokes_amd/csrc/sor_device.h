@@ -66,11 +66,12 @@ __device__ __forceinline__ void sor_batch(T* pw, const T* cw, int nx, int ny, in
 constexpr int kSorLag = 3;
 
 __device__ __forceinline__ float lane_before(float x) {       // lane l <- lane l - 1 (wave rotate right by one)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, true));
 }
 __device__ __forceinline__ double lane_before(double x) {
     const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x13C, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x13C, 0xF, 0xF, false);
+    // (a whole-wave rotate reads a valid lane everywhere: no `old` operand to initialise)
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, 0x13C, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x13C, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
@@ -114,13 +115,14 @@ __device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int n
     int epos = -wave * kSorLag - nfronts, esweep = wave;
     T emax = (T)0, edone = (T)0, own = (T)0;
     T qe = (T)0, qs = (T)0, qo = (T)0, qc = (T)0, qn = (T)0, qw = (T)0;       // the operands of this lane's next point, requested a step ahead
-    auto request = [&](int ps, int sw) {
-        if (has_row && sw < nsw && ps >= 0 && ps < ncol) {
-            const int c = row + ps + 1;
-            qe = pw[c + 1]; qs = pw[c + ny]; qo = pw[c]; qc = cw[c]; qn = pw[c - ny]; qw = pw[c - 1];
-        }
+    // (pos < 0 is a huge unsigned number: one comparison for 0 <= pos < ncol)
+    auto live = [&](int ps, int sw) { return has_row && sw < nsw && (unsigned)ps < (unsigned)ncol; };
+    auto request = [&](int ps) {
+        const int c = row + ps + 1;
+        qe = pw[c + 1]; qs = pw[c + ny]; qo = pw[c]; qc = cw[c]; qn = pw[c - ny]; qw = pw[c - 1];
     };
-    request(pos, sweep);
+    bool act = live(pos, sweep);                                               // this step's activity = what last step's request was issued under
+    if (act) request(pos);
 #if NNS_SOR_TIMING
     long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tcomp = 0, treq = 0, tbar = 0;
 #endif
@@ -138,7 +140,7 @@ __device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int n
             epos = -P; esweep += kSorWaves;
         }
         const T north = lane_before(own);                                      // p[i-1][j] of THIS sweep (before any lane moves on)
-        if (has_row && sweep < nsw && pos >= 0 && pos < ncol) {
+        if (act) {
             const T n_ = i == 1 ? qn : north, w_ = pos == 0 ? qw : own;          // boundary values come from the grid, interior ones from registers
             const T nw = (div_den<T>(k.beta * (k.dy2 * qs + k.dy2 * n_ + k.dx2 * qe + k.dx2 * w_ - qc), k) + k.omb * qo);  // :193-196
             pw[row + pos + 1] = nw;
@@ -151,7 +153,8 @@ __device__ __forceinline__ void sor_batch_rows(T* pw, const T* cw, int nx, int n
 #if NNS_SOR_TIMING
         if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tq1 = clock64(); }
 #endif
-        request(pos, sweep);
+        act = live(pos, sweep);
+        if (act) request(pos);
 #if NNS_SOR_TIMING
         if (timed) { __builtin_amdgcn_s_waitcnt(0xc07f); tq2 = clock64(); }
 #endif
