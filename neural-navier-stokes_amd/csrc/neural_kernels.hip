@@ -236,6 +236,8 @@ __global__ __launch_bounds__(NT) void ode_mlp_fwd_kernel(const float* __restrict
 #define NNS_ROW_TIMING 0             // 1: the row kernel prints the cycles of one evaluation's four phases (s_memtime)
 #endif
 constexpr int RT = 256;            // threads per row workgroup: one wave per SIMD
+// (Round 4, measured and not kept: EIGHT waves -- a quarter row per thread, the quarters of an output in four adjacent lanes meeting in two DPP adds, two waves
+// per SIMD: 324 us per 100 RK4 steps against 296 for this kernel, same box: the three barriers per evaluation get dearer, the shorter FMA chains buy less.)
 // Round 3: four waves instead of two.  With 128 threads a thread carried a whole row of W1 -- 128 dependent-issue FMAs per evaluation on
 // a SIMD that issues one vector instruction every ~5 cycles to a lone wave: ~3000 cycles per evaluation, 530 us per 100 RK4 steps.  Now
 // thread (n, half) holds HALF a row (layer 1: 16 of 32 inputs, layer 2: 64 of 128), the two halves sit in lanes l and l + 32 of one wave and
