@@ -26,8 +26,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int H = 128;            // hidden width of ODEFunc (fixed in the reference)
 constexpr int KP = 32;            // padded coefficient count (K <= 32: K = 3 * n_coeffs = 30 in the reference driver)
-constexpr int HS = 132;           // LDS row stride of [*][128] images (pad 4: A-fragment reads 2-way at worst)
-constexpr int KS = 36;            // LDS row stride of [*][KP] images
+constexpr int HS = 130;           // LDS row stride of [*][128] images: = 2 (mod 32), so the 16 rows x 2 adjacent columns of an A-fragment or transposed-B read hit 32 distinct banks (round 4; 132 = 4 mod 32 made them 2-way)
+constexpr int KS = 34;            // LDS row stride of [*][KP] images (= 2 mod 32, as HS)
 constexpr int TB = 16;            // batch rows per workgroup
 constexpr int NT = 256;           // threads per workgroup (4 waves)
 
