@@ -339,9 +339,42 @@ class NavierStokesSystem():
         apply_list(v, self.v_bc)
         return u, v, p
 
-    def simulate(self):
+    def simulate(self, use_graph=None):
+        """The time loop (:343-362).  A step is ~90 launches of 2-7 us on 51 x 51 matrices -- bound by what the HOST needs to enqueue them (0.56 ms
+        per step, profiles/r04_small_paths.txt) -- and every step runs the same kernels on the same buffers, so by default ONE step is captured
+        as a HIP graph and replayed (use_graph=False: the eager loop; a capture that fails falls back to it).  Same kernels, same order: the
+        trajectories are bitwise those of the eager loop (test)."""
         u, v, p = (self._dev(a) for a in self._init_variables())
         u1, v1 = u.clone(), v.clone()
+        if use_graph is None:
+            use_graph = u.is_cuda
+        graph = None
+        if use_graph and self.nt > 2:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                       # lazy initialisation inside the launchers happens here, not in the capture
+                    a, b = self._predict_dev(u.clone(), v.clone(), u1.clone(), v1.clone())
+                    self._correct_dev(a, b, p.clone())
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    ui, vi = self._predict_dev(u, v, u1, v1)
+                    _u, _v, _p = self._correct_dev(ui, vi, p)
+                    u1.copy_(u), v1.copy_(v)
+                    u.copy_(_u), v.copy_(_v), p.copy_(_p)
+            except Exception as e:                                   # noqa: BLE001 -- the eager loop is the same computation
+                print('chorin_spectral: HIP graph capture of the step failed (%r): running eagerly' % (e,))
+                graph = None
+                u, v, p = (self._dev(a) for a in self._init_variables())
+                u1, v1 = u.clone(), v.clone()
+        if graph is not None:
+            us = torch.empty((self.nt,) + tuple(u.shape), dtype=u.dtype, device=u.device)
+            vs, ps = torch.empty_like(us), torch.empty_like(us)
+            for n in range(self.nt):
+                graph.replay()
+                us[n].copy_(u), vs[n].copy_(v), ps[n].copy_(p)
+            return us.cpu().numpy(), vs.cpu().numpy(), ps.cpu().numpy()
         us, vs, ps = [], [], []
         for n in range(self.nt):
             ui, vi = self._predict_dev(u, v, u1, v1)

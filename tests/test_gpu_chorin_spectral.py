@@ -193,3 +193,23 @@ def test_corrected_projection_is_well_conditioned(N, gpu_device):
     div = s.Dx[1:-1, :] @ got[0][:, 1:-1] + got[1][1:-1, :] @ s.Dy[1:-1, :].T
     div0 = s.Dx[1:-1, :] @ ui[:, 1:-1] + vi[1:-1, :] @ s.Dy[1:-1, :].T
     assert np.abs(div - div.mean()).max() < 1e-9 * np.abs(div0).max()
+
+
+@pytest.mark.parametrize('matrices', ['reference', 'corrected'])
+def test_simulate_replayed_from_a_hip_graph_is_bitwise_the_eager_loop(matrices, gpu_device):
+    """Round 4: `simulate` captures ONE step (the ~90 launches of predictor + correction on N x N matrices) as a HIP graph and replays it; the
+    trajectories must be bitwise those of the eager loop -- same kernels in the same order on the same buffers."""
+    from src.chorin_spectral.simulate import NavierStokesSystem
+    from src.boundary import DirichletBoundaryCondition as D
+    N = 17
+    h = 2. / N
+    lid = [D(0.0, 'left', h, h), D(0.0, 'right', h, h), D(1.0, 'top', h, h), D(0.0, 'bottom', h, h)]
+    wall = [D(0.0, s, h, h) for s in ('left', 'right', 'top', 'bottom')]
+    rng = np.random.default_rng(4)
+    ic = [1e-3 * rng.standard_normal((N, N)) for _ in range(3)]
+    runs = []
+    for g in (True, False):
+        s = NavierStokesSystem(ic[0].copy(), ic[1].copy(), ic[2].copy(), lid, wall, nt=8, nit=1, nx=N, ny=N, dt=1e-4, rho=1.0, nu=1.0, matrices=matrices)
+        runs.append(s.simulate(use_graph=g))
+    for a, b in zip(*runs):
+        assert a.shape == (8, N, N) and np.isfinite(a).all() and np.array_equal(a, b)
