@@ -1,0 +1,15 @@
+import os, sys
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'neural-navier-stokes_amd'))
+import numpy as np, torch
+from nns import ops
+rng = np.random.default_rng(0); out = {}
+for ci, (nx, ny) in enumerate([(50, 50), (64, 64), (33, 47), (5, 5), (70, 70), (96, 40)]):
+    for dtype in (torch.float64, torch.float32):
+        for nit in (1, 7, 50):
+            p = torch.as_tensor(rng.standard_normal((2, nx, ny)), dtype=dtype, device='cuda'); b = torch.as_tensor(rng.standard_normal((2, nx, ny)), dtype=dtype, device='cuda')
+            bl = ops.make_bc_list([('neumann', 'right', 0.1, 0.03, 0.04), ('dirichlet', 'top', 0.0, 0.03, 0.04), ('neumann', 'left', 0.0, 0.03, 0.04), ('neumann', 'bottom', -0.2, 0.03, 0.04)]) if False else None
+            from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
+            bcs = [N(0.1, 'right', 0.03, 0.04), D(0., 'top', 0.03, 0.04), N(0., 'left', 0.03, 0.04), N(-0.2, 'bottom', 0.03, 0.04)]
+            ops.fd_jacobi_(p, b, 0.03, 0.04, nit, bcs)
+            out['c%d_%s_%d' % (ci, str(dtype)[6:], nit)] = p.cpu().numpy()
+np.savez(sys.argv[1], **out); print('wrote', len(out))
