@@ -1,3 +1,5 @@
+"""Developer helper (GPU box): the Jacobi pressure solve of direct_fd (nns_fd_jacobi_*) over shapes / dtypes / sweep counts into an .npz, to compare two
+libraries bitwise:  python tools/jac_ab.py a.npz; NNS_LIB_PATH=... python tools/jac_ab.py b.npz; python tools/sor_ab.py --compare a.npz b.npz"""
 import os, sys
 sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'neural-navier-stokes_amd'))
 import numpy as np, torch
@@ -7,7 +9,6 @@ for ci, (nx, ny) in enumerate([(50, 50), (64, 64), (33, 47), (5, 5), (70, 70), (
     for dtype in (torch.float64, torch.float32):
         for nit in (1, 7, 50):
             p = torch.as_tensor(rng.standard_normal((2, nx, ny)), dtype=dtype, device='cuda'); b = torch.as_tensor(rng.standard_normal((2, nx, ny)), dtype=dtype, device='cuda')
-            bl = ops.make_bc_list([('neumann', 'right', 0.1, 0.03, 0.04), ('dirichlet', 'top', 0.0, 0.03, 0.04), ('neumann', 'left', 0.0, 0.03, 0.04), ('neumann', 'bottom', -0.2, 0.03, 0.04)]) if False else None
             from nns.boundary import DirichletBoundaryCondition as D, NeumannBoundaryCondition as N
             bcs = [N(0.1, 'right', 0.03, 0.04), D(0., 'top', 0.03, 0.04), N(0., 'left', 0.03, 0.04), N(-0.2, 'bottom', 0.03, 0.04)]
             ops.fd_jacobi_(p, b, 0.03, 0.04, nit, bcs)
