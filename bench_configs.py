@@ -239,7 +239,10 @@ def secondary(cpu=True):
     t1 = timeit(lambda: sysm.simulate_device(use_graph=False), iters=2, warm=1) / nt
     S = 49                                                                  # at most nit - 1 sweeps (:183,:190)
     b1 = (56 + 12 * S) * 2.0 * n * n                                        # 56 + 12 S B/pt in float32, x 2 for float64
-    out['cfg1_chorin_fd_64_step'] = dict(ms=1e3 * t1, grid_point_steps_per_s=n * n / t1, dtype='f64', bound='latency (sequential SOR fronts of ONE 64^2 grid; HBM row for scale)',
+    sys_si = NavierStokesSystem(z, z.copy(), z.copy(), u_bc, v_bc, p_bc, nt=nt, nit=50, nx=n, ny=n, dt=1e-3, rho=1, nu=0.02, beta=1.25, method='semi_implicit')
+    t1si = timeit(lambda: sys_si.simulate_device(use_graph=False), iters=2, warm=1) / nt
+    out['cfg1_chorin_fd_64_step'] = dict(ms=1e3 * t1, semi_implicit_ms=1e3 * t1si, method='explicit (the line BASELINE config 1 is timed on); semi_implicit_ms = the reference driver\'s default method',
+                                         grid_point_steps_per_s=n * n / t1, dtype='f64', bound='latency (sequential SOR fronts of ONE 64^2 grid; HBM row for scale)',
                                          algorithmic_bytes=b1, achieved=b1 / t1 / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=b1 / t1 / 1e9 / HBM_PEAK_GBS,
                                          cpu_baseline=cpu_baseline_cfg1() if cpu else None)
     # ---- cfg 2: neural_spectral 128 x 128, K = 10, nt = 100, mb = 1: one training iteration (src/neural_spectral/spectral_ode.py:178-190)
