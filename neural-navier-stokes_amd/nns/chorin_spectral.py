@@ -235,18 +235,22 @@ class NavierStokesSystem():
         kx, ky = self._k[name]
         g = self._bc[name]
         ni, nj = sol.shape
-        def vec(b, const, n, left):
+        cache = self.__dict__.setdefault('_bvec_dev', {})       # the b-vectors are constants of the set-up: on the device ONCE (they were copied from
+                                                                # the host in every step, which also kept a step from being captured as a HIP graph)
+        def vec(key, b, const, n, left):
             out = torch.full((n,), float(const), dtype=torch.float64, device=self.device)
             if np.any(b != 0):
-                bt = self._dev(b[None, :] if left else b[:, None])
+                bt = cache.get((name, key))
+                if bt is None:
+                    bt = cache[(name, key)] = self._dev(b[None, :] if left else b[:, None])
                 prod = ops.cheb_gemm(bt, sol) if left else ops.cheb_gemm(sol, bt)
                 out = out + prod.reshape(-1)
             return out.contiguous()
         corr = self.matrices == 'corrected'       # the reference leaves the constant of the last row / column out (:250,:253)
-        x0 = vec(kx['b0'] / kx['e'], (kx['c0_minus'] * g['g_minus_x'] + kx['c0_plus'] * g['g_plus_x']) / kx['e'], nj, True)
-        xN = vec(kx['bN'] / kx['e'], kx['cN'] if corr else 0.0, nj, True)
-        y0 = vec(ky['b0'] / ky['e'], (ky['c0_minus'] * g['g_minus_y'] + ky['c0_plus'] * g['g_plus_y']) / ky['e'], ni, False)
-        yN = vec(ky['bN'] / ky['e'], ky['cN'] if corr else 0.0, ni, False)
+        x0 = vec('x0', kx['b0'] / kx['e'], (kx['c0_minus'] * g['g_minus_x'] + kx['c0_plus'] * g['g_plus_x']) / kx['e'], nj, True)
+        xN = vec('xN', kx['bN'] / kx['e'], kx['cN'] if corr else 0.0, nj, True)
+        y0 = vec('y0', ky['b0'] / ky['e'], (ky['c0_minus'] * g['g_minus_y'] + ky['c0_plus'] * g['g_plus_y']) / ky['e'], ni, False)
+        yN = vec('yN', ky['bN'] / ky['e'], ky['cN'] if corr else 0.0, ni, False)
         return x0, xN, y0, yN
 
     def _predict_dev(self, un, vn, un1, vn1):
@@ -284,8 +288,14 @@ class NavierStokesSystem():
         mm(vi[1:-1, :].contiguous(), F['Dy'], transB=True, beta=1.0, out=div)                      # + v*[1:-1, :] @ Dy[1:-1, :]^T
         Hh = mm(mm(D['PP_inv'], div, alpha=self.rho / self.dt), D['PQ_inv'], transB=True)
         Qh = ops.cheb_diag_div(Hh, D['lpx'], D['lpy'], 0.0, 1.0, 1.0)
-        for i, j in self._null:
-            Qh[i, j] = 0.0                                                                          # pressure is defined up to a constant
+        if len(self._null):                                                                         # pressure is defined up to a constant
+            mask = self.__dict__.get('_null_mask_dev')
+            if mask is None:                                                                        # (built once, outside any graph capture: the warm-up step)
+                m = np.zeros(tuple(Qh.shape), dtype=bool)
+                for i, j in self._null:
+                    m[i, j] = True
+                mask = self._null_mask_dev = torch.as_tensor(m, device=Qh.device)
+            Qh.masked_fill_(mask, 0.0)
         Q = mm(D['PP'], mm(Qh, D['PQ'], transB=True))
         I = lambda a: a[1:-1, 1:-1].contiguous()
         ui_i, vi_i = I(ui), I(vi)
@@ -368,6 +378,7 @@ class NavierStokesSystem():
                 graph = None
                 u, v, p = (self._dev(a) for a in self._init_variables())
                 u1, v1 = u.clone(), v.clone()
+        self.last_simulate_used_graph = graph is not None
         if graph is not None:
             us = torch.empty((self.nt,) + tuple(u.shape), dtype=u.dtype, device=u.device)
             vs, ps = torch.empty_like(us), torch.empty_like(us)

@@ -211,5 +211,6 @@ def test_simulate_replayed_from_a_hip_graph_is_bitwise_the_eager_loop(matrices, 
     for g in (True, False):
         s = NavierStokesSystem(ic[0].copy(), ic[1].copy(), ic[2].copy(), lid, wall, nt=8, nit=1, nx=N, ny=N, dt=1e-4, rho=1.0, nu=1.0, matrices=matrices)
         runs.append(s.simulate(use_graph=g))
+        assert s.last_simulate_used_graph == g                       # (a capture that fails falls back to the eager loop: that must not be what passes here)
     for a, b in zip(*runs):
         assert a.shape == (8, N, N) and np.isfinite(a).all() and np.array_equal(a, b)
