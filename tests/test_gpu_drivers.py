@@ -18,6 +18,7 @@ def run(script, args, cwd):
     env = dict(os.environ, PYTHONPATH=PKG)
     r = subprocess.run([sys.executable, os.path.join(PKG, 'src', script)] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    return r
 
 
 def test_chorin_fd_driver_then_neural_training_driver(tmp_path, gpu_device):
@@ -31,7 +32,8 @@ def test_chorin_fd_driver_then_neural_training_driver(tmp_path, gpu_device):
     assert np.load(os.path.join(d, 'data.npz'))['p'].shape == (3, 16, 16)
     for script in ('neural_spectral/spectral_ode.py', 'neural_spectral/spectral_ode2.py'):
         out = os.path.join(d, 'ck_' + os.path.basename(script)[:-3])
-        run(script, ['--npz-path', os.path.join(d, 'data_explicit.npz'), '--out-dir', out, '--n-iters', '20', '--n-coeffs', '4'], d)
+        r = run(script, ['--npz-path', os.path.join(d, 'data_explicit.npz'), '--out-dir', out, '--n-iters', '20', '--n-coeffs', '4'], d)
+        assert 'graph capture' not in r.stdout                       # the iteration really was replayed from its HIP graph (a failed capture falls back and says so)
         ck = torch.load(os.path.join(out + '_4', 'checkpoint.pth.tar'), weights_only=False)
         assert sorted(ck.keys()) == ['config', 'losses', 'model_state_dict', 'optimizer_state_dict', 'penalties']
         assert ck['losses'].shape == (20,) and ck['losses'][-1] < ck['losses'][0]       # it trains
