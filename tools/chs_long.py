@@ -1,3 +1,5 @@
+"""Developer helper (GPU box): 1500 steps of chorin_spectral (matrices='corrected', N = 33) with the step replayed from its HIP graph against the eager loop:
+time per step, finiteness, bitwise equality of the trajectories, device-memory growth."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'neural-navier-stokes_amd'))
 import numpy as np, torch
