@@ -46,6 +46,19 @@ __device__ __forceinline__ void bc_apply_list(P A, int nx, int ny, const BcListD
 }
 
 
+// The same list applied by ONE wave (the caller's other waves wait at the barrier that follows): inside a wave the entries are ordered by the LDS
+// queue itself, so a list of four entries costs no workgroup barrier instead of four -- what a sweep-per-barrier loop (the Jacobi solve of
+// direct_fd: the list after EVERY sweep) is made of.  A must be LDS (a wave's global stores are not ordered for its own later loads without a wait).
+template <typename T, typename P>
+__device__ __forceinline__ void bc_apply_list_one_wave(P A, int nx, int ny, const BcListDev<T>& bcs, int lane) {
+    for (int k = 0; k < bcs.n; ++k) {
+        bc_apply_one<T>(A, nx, ny, bcs.kind[k], bcs.side[k], bcs.value[k], bcs.dx[k], bcs.dy[k], lane, kWave);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // chorin_fd._explicit_predictor_step  (src/chorin_fd/simulate.py:63-91)
 // ------------------------------------------------------------------------------------------

@@ -672,8 +672,8 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(T* __restrict__ p, con
             nxt[i * ny + j] = cur[i * ny + j];
         }
         __syncthreads();
-        bc_apply_list<T>(nxt, nx, ny, bcs, tid, nt);
-        if (bcs.n == 0) __syncthreads();
+        if (tid < kWave) bc_apply_list_one_wave<T>(nxt, nx, ny, bcs, tid);       // (round 4: one wave, no barrier per entry: 5-6 barriers per sweep became 2)
+        __syncthreads();
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
     for (int c = tid; c < n; c += nt) g[c] = cur[c];
